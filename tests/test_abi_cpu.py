@@ -1,0 +1,58 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/turbosqueeze_amd.h and
+include/turbosqueeze.h declare; without a GPU every compute entry point fails loudly (no CPU
+fallback, nothing routed through oracle/)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+import turbosqueeze_amd as tsq
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = set()
+    for h in ("turbosqueeze_amd.h", "turbosqueeze.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(tsqa?_?[A-Za-z_0-9]*)\s*\(", src))
+    return {n for n in names if n.startswith("tsq") and not n.endswith("_fn")}
+
+
+def test_library_exports_every_declared_symbol():
+    L = tsq.lib()
+    missing = [n for n in sorted(declared_symbols()) if not hasattr(L, n)]
+    assert not missing, missing
+    assert len(declared_symbols()) >= 28
+
+
+def test_product_does_not_link_or_import_the_oracle():
+    out = subprocess.run(["ldd", tsq.lib_path()], capture_output=True, text=True).stdout
+    assert "tsq_oracle" not in out and "tsq_ref" not in out
+    for root, _, files in os.walk(os.path.join(ROOT, "turbosqueeze_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".h", ".c", ".cpp")):
+                text = open(os.path.join(root, f), errors="ignore").read()
+                assert "pyoracle" not in text and "tsq_oracle" not in text and "oracle/" not in text, f
+
+
+def test_sizes_helpers():
+    L = tsq.lib()
+    assert L.tsqa_block_count(1) == 1 and L.tsqa_block_count(1 << 22) == 1 and L.tsqa_block_count((1 << 22) + 1) == 2
+    assert L.tsqa_block_count(10**9) == 239
+    assert tsq.container_bound(10**9) == 16 + 239 * (3 + tsq.OUTPUT_SZ)
+
+
+def test_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(tsq.TsqError):
+        tsq.DeviceCodec(0)
+    with pytest.raises(tsq.TsqError):
+        tsq.tsq_encode(b"some bytes to encode", 0)
+    assert tsq.tsq_decode(b"\x05\x00\x00\xff\x40hello", 0) == b""
+    with pytest.raises(tsq.TsqError):
+        tsq.tsq_compress_mt(b"x" * 100, False)

@@ -1,0 +1,202 @@
+"""GPU parity tests: every call goes through the C ABI (libturbosqueeze_amd.so) and is compared
+byte for byte with the oracle (oracle/tsq_oracle.c) and with the committed golden fixtures the
+compiled reference produced.  Integer/byte work: the bar is bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fuzzgen
+import kat
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = kat.GOLDEN
+MANIFEST = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+SMALL = sorted(k for k in MANIFEST if os.path.exists(os.path.join(GOLDEN, k + ".in")))
+
+
+@pytest.fixture(scope="module")
+def tsq():
+    import torch
+    assert torch.cuda.is_available()
+    import turbosqueeze_amd
+    return turbosqueeze_amd
+
+
+@pytest.fixture(scope="module")
+def codec(tsq):
+    c = tsq.DeviceCodec(0)
+    yield c
+    c.close()
+
+
+def to_dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def to_bytes(t):
+    return bytes(t.cpu().numpy())
+
+
+# ---------------------------------------------------------------- single-block API (tsqEncode/tsqDecode)
+
+@pytest.mark.parametrize("name", SMALL)
+def test_golden_fixture_block_api(tsq, name):
+    data = open(os.path.join(GOLDEN, name + ".in"), "rb").read()
+    for ext, tag in ((0, "noext"), (1, "ext")):
+        want = open(os.path.join(GOLDEN, f"{name}.{tag}"), "rb").read()
+        assert tsq.tsq_encode(data, ext) == want
+        assert tsq.tsq_decode(want, ext) == data
+
+
+def test_k0_k1b_exact_bytes(tsq):
+    for ext in (0, 1):
+        assert tsq.tsq_encode(bytes(kat.KATS["K0"][0]()), ext).hex() == kat.K0_STREAM_HEX
+        assert tsq.tsq_encode(b"A", ext).hex() == kat.K1B_STREAM_HEX
+
+
+@pytest.mark.parametrize("name", sorted(kat.KATS))
+def test_known_answer_vectors(tsq, oracle, name):
+    make, n, sizes, _ = kat.KATS[name]
+    data = bytes(make())
+    for ext in (0, 1):
+        out = tsq.tsq_encode(data, ext)
+        assert len(out) == sizes[ext]
+        assert out == oracle.encode_block(data, ext)
+        if name in MANIFEST:
+            assert "%016x" % oracle.fnv(out) == MANIFEST[name]["ext" if ext else "noext"]["fnv"]
+        assert tsq.tsq_decode(out, ext) == data
+
+
+def test_reference_test_scenario(tsq):
+    """test/test.cpp:30-54: tsqEncode -> tsqDecode of the 699-byte string with extensions."""
+    data = bytes(kat.k1_input())
+    out = tsq.tsq_encode(data, 1)
+    assert tsq.tsq_decode(out, 1) == data
+
+
+def test_decode_rejects_bad_streams(tsq, oracle):
+    assert tsq.tsq_decode(b"\xff\xff\xff\x00", 0) == b""                       # size header > 4 MiB
+    assert tsq.tsq_decode(b"\x10\x00\x00\x00\x30\x05\x00", 0) == b""           # source before block start
+    good = oracle.encode_block(b"hello hello hello hello hello", 0)
+    assert tsq.tsq_decode(good[:-3], 0) == b""                                 # truncated
+
+
+# ---------------------------------------------------------------- device-resident container path
+
+def test_fuzz_containers_vs_oracle(codec, oracle):
+    rng = np.random.default_rng(2024)
+    for case in range(int(os.environ.get("TSQ_GPU_FUZZ", "120"))):
+        n = int(rng.integers(1, 200000)) if case % 4 else int(rng.integers(1, 64))
+        data = fuzzgen.structured(rng, n)
+        for ext in (0, 1):
+            blob = codec.compress(to_dev(data), ext)
+            assert to_bytes(blob) == oracle.compress(data, ext), (case, n, ext)
+            assert to_bytes(codec.decompress(blob)) == data.tobytes(), (case, n, ext)
+
+
+def test_multiblock_halo_and_short_tail(codec, oracle, tsq):
+    """Blocks are contiguous: block k's look-ahead reads block k+1 (SURVEY.md 8c canonical conditions)."""
+    n = 3 * (1 << 22) + 77777
+    host = tsq.synth.text(n, seed=11)
+    host[(1 << 22) - 40:(1 << 22) + 40] = np.resize(np.frombuffer(b"crossing-the-block-edge ", dtype=np.uint8), 80)
+    dev = to_dev(host)
+    for ext in (0, 1):
+        blob = codec.compress(dev, ext)
+        want = oracle.compress(host, ext, threads=4)
+        got = to_bytes(blob)
+        assert got[:16] == want[:16]
+        assert got == want
+        import torch
+        assert torch.equal(codec.decompress(blob), dev)
+
+
+@pytest.mark.parametrize("kind", ["zeros", "random", "mix"])
+def test_config5_inputs(codec, oracle, tsq, kind):
+    n = 2 * (1 << 22) + 12345
+    host = {"zeros": lambda: np.zeros(n, dtype=np.uint8), "random": lambda: tsq.synth.random_bytes(n, 5),
+            "mix": lambda: tsq.synth.mix(n, 5)}[kind]()
+    blob = codec.compress(to_dev(host), 1)
+    assert to_bytes(blob) == oracle.compress(host, 1, threads=4)
+    assert to_bytes(codec.decompress(blob)) == host.tobytes()
+
+
+def test_enwik8_sized_bit_exact(codec, oracle, tsq):
+    """BASELINE.json config 2: 100 MB, --no-ext, bit-exact vs the CPU path."""
+    import torch
+    n = 100_000_000
+    host = tsq.synth.text(n, seed=8)
+    dev = to_dev(host)
+    blob = codec.compress(dev, 0)
+    want = oracle.compress(host, 0, threads=os.cpu_count() or 8)
+    assert blob.numel() == len(want)
+    assert to_bytes(blob) == want
+    assert torch.equal(codec.decompress(blob), dev)
+
+
+def test_enwik9_sized_roundtrip_properties(codec, oracle, tsq):
+    """BASELINE.json config 3 at full size: round trip identity, container structure, and a sampled
+    block compared with the oracle (size-independent properties; full compare is config 2)."""
+    import torch
+    n = 1_000_000_000
+    host = tsq.synth.text(n, seed=9)
+    dev = to_dev(host)
+    blob = codec.compress(dev, 0)
+    head = to_bytes(blob[:16])
+    assert head[:4] == b"TSQ1" and int.from_bytes(head[4:8], "little") == 239
+    assert int.from_bytes(head[8:16], "little") == n
+    ratio = blob.numel() / n
+    assert 0.60 < ratio < 0.64, ratio
+    back = codec.decompress(blob)
+    assert torch.equal(back, dev)
+    # walk the frames on the host and check three blocks against the oracle
+    raw = blob.cpu().numpy()
+    at, frames = 16, []
+    for _ in range(239):
+        ln = int(raw[at]) | int(raw[at + 1]) << 8 | (int(raw[at + 2]) & 0x7F) << 16
+        frames.append((at + 3, ln))
+        at += 3 + ln
+    assert at == raw.size
+    for b in (0, 117, 238):
+        lo = b << 22
+        hi = min(n, lo + (1 << 22))
+        want = oracle.encode_block(host[lo:hi], 0, halo=bytes(host[hi:hi + 128]))
+        s, ln = frames[b]
+        assert bytes(raw[s:s + ln]) == want, b
+
+
+def test_container_errors(codec, tsq, oracle):
+    good = oracle.compress(tsq.synth.text(300000, 2), 0)
+    bad_magic = b"TSQ2" + good[4:]
+    zero_blocks = good[:4] + (0).to_bytes(4, "little") + good[8:]
+    truncated = good[: len(good) // 2]
+    big_frame = good[:16] + b"\xff\xff\x7f" + good[19:]
+    for blob in (bad_magic, zero_blocks, truncated, big_frame):
+        with pytest.raises(tsq.TsqError):
+            codec.decompress(to_dev(np.frombuffer(blob, dtype=np.uint8)), out_cap=400000)
+    # corrupt an offset inside the stream: must be flagged, not crash
+    arr = np.frombuffer(good, dtype=np.uint8).copy()
+    arr[40:60] = 0xFF
+    try:
+        out = codec.decompress(to_dev(arr), out_cap=400000)
+        assert out.numel() == 300000          # decoded to *something* of the right size, or raised
+    except tsq.TsqError:
+        pass
+    assert to_bytes(codec.decompress(to_dev(np.frombuffer(good, dtype=np.uint8)))) == bytes(tsq.synth.text(300000, 2))
+
+
+def test_serial_and_fast_kernels_agree(tsq, oracle):
+    c = tsq.DeviceCodec(0)
+    host = tsq.synth.text(9_000_000, seed=21)
+    dev = to_dev(host)
+    outs = []
+    for variant in (0, 1):
+        c.set_variant(variant, variant)
+        blob = c.compress(dev, 1)
+        outs.append(to_bytes(blob))
+        assert to_bytes(c.decompress(blob)) == host.tobytes()
+    assert outs[0] == outs[1] == oracle.compress(host, 1, threads=4)
+    c.close()

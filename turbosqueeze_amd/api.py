@@ -1,0 +1,274 @@
+"""ctypes binding of libturbosqueeze_amd.so (include/turbosqueeze_amd.h).
+
+Two faces:
+  * DeviceCodec  -- tsqa_* device-resident entry points over torch CUDA(HIP) tensors.
+    torch is used only for device memory and streams.
+  * tsq_encode / tsq_decode / tsq_compress_mt / tsq_decompress_mt -- the reference's own
+    API names (turbosqueeze.h:508,580,657,670) over host bytes, same argument meaning.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BLOCK_SZ = 1 << 22
+OUTPUT_SZ = BLOCK_SZ + (BLOCK_SZ >> 2)
+
+ERRORS = {1: "no usable gfx950 device", 2: "HIP runtime error", 3: "bad argument", 4: "malformed container",
+          5: "malformed block stream", 6: "block expanded beyond TSQ_OUTPUT_SZ"}
+
+
+class TsqError(RuntimeError):
+    def __init__(self, code: int, detail: str = ""):
+        self.code = code
+        super().__init__(f"turbosqueeze_amd error {code} ({ERRORS.get(code, '?')}) {detail}".strip())
+
+
+def lib_path() -> str:
+    return os.path.join(HERE, "libturbosqueeze_amd.so")
+
+
+def build_native(force: bool = False) -> None:
+    """Compile every HIP source for gfx950 into turbosqueeze_amd/*.so (in-tree)."""
+    csrc = os.path.join(HERE, "csrc")
+    args = ["make", "-C", csrc, "all"]
+    if force:
+        subprocess.check_call(["make", "-C", csrc, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the native library.  Fails loudly when it is missing: there is no other path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); turbosqueeze_amd has no CPU fallback")
+    L = C.CDLL(path)
+    vp, u8pp, szp = C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)
+    L.tsqa_create.restype = C.c_int
+    L.tsqa_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.tsqa_destroy.restype = None
+    L.tsqa_destroy.argtypes = [vp]
+    L.tsqa_last_error.restype = C.c_char_p
+    L.tsqa_last_error.argtypes = [vp]
+    L.tsqa_device_id.restype = C.c_int
+    L.tsqa_device_id.argtypes = [vp]
+    L.tsqa_block_count.restype = C.c_size_t
+    L.tsqa_block_count.argtypes = [C.c_size_t]
+    L.tsqa_container_bound.restype = C.c_size_t
+    L.tsqa_container_bound.argtypes = [C.c_size_t]
+    L.tsqa_compress_device.restype = C.c_int
+    L.tsqa_compress_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, szp, C.c_uint32, vp]
+    L.tsqa_compress_device_async.restype = C.c_int
+    L.tsqa_compress_device_async.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp, C.c_uint32, vp]
+    L.tsqa_decompress_device.restype = C.c_int
+    L.tsqa_decompress_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, szp, vp]
+    L.tsqa_decompress_device_async.restype = C.c_int
+    L.tsqa_decompress_device_async.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp, C.c_size_t, vp, vp, vp]
+    L.tsqa_profile_enable.restype = C.c_int
+    L.tsqa_profile_enable.argtypes = [vp, C.c_int]
+    L.tsqa_profile_read.restype = C.c_int
+    L.tsqa_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+    L.tsqa_set_kernel_variant.restype = None
+    L.tsqa_set_kernel_variant.argtypes = [vp, C.c_int, C.c_int]
+    # reference API
+    L.tsqAllocateContext.restype = vp
+    L.tsqDeallocateContext.argtypes = [vp]
+    L.tsqInit.argtypes = [vp]
+    L.tsqEncode.restype = None
+    L.tsqEncode.argtypes = [vp, vp, vp, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32]
+    L.tsqDecode.restype = None
+    L.tsqDecode.argtypes = [vp, vp, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32]
+    L.tsqAllocateContextCompression_MT.restype = vp
+    L.tsqAllocateContextCompression_MT.argtypes = [C.c_bool]
+    L.tsqDeallocateContextCompression_MT.argtypes = [vp]
+    L.tsqAllocateContextDecompression_MT.restype = vp
+    L.tsqAllocateContextDecompression_MT.argtypes = [C.c_bool]
+    L.tsqDeallocateContextDecompression_MT.argtypes = [vp]
+    L.tsqCompress_MT.restype = C.c_bool
+    L.tsqCompress_MT.argtypes = [vp, vp, C.c_size_t, C.c_bool, u8pp, szp, C.c_bool, C.c_bool, C.c_uint32]
+    L.tsqDecompress_MT.restype = C.c_bool
+    L.tsqDecompress_MT.argtypes = [vp, vp, C.c_size_t, C.c_bool, u8pp, szp, C.c_bool]
+    L.tsqa_compress_async_cb.restype = C.c_uint32
+    L.tsqa_compress_async_cb.argtypes = [vp, vp, C.c_size_t, C.c_bool, u8pp, szp, C.c_bool, C.c_bool, C.c_uint32, vp, vp, vp]
+    L.tsqa_decompress_async_cb.restype = C.c_uint32
+    L.tsqa_decompress_async_cb.argtypes = [vp, vp, C.c_size_t, C.c_bool, u8pp, szp, C.c_bool, vp, vp, vp]
+    _lib = L
+    return L
+
+
+DONE_FN = C.CFUNCTYPE(None, C.c_uint32, C.c_bool, C.c_void_p)
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_uint32, C.c_double, C.c_void_p)
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+def container_bound(n: int) -> int:
+    return int(lib().tsqa_container_bound(n))
+
+
+class DeviceCodec:
+    """Device-resident compress/decompress over torch uint8 CUDA tensors (tsqa_* C ABI)."""
+
+    def __init__(self, device: int = -1):
+        import torch
+        if not torch.cuda.is_available():
+            raise TsqError(1, "torch sees no GPU")
+        self.torch = torch
+        self.L = lib()
+        self.h = C.c_void_p()
+        if device < 0:
+            device = torch.cuda.current_device()
+        rc = self.L.tsqa_create(device, C.byref(self.h))
+        if rc:
+            raise TsqError(rc)
+        self.device = torch.device("cuda", device)
+        self._size = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def close(self):
+        if self.h:
+            self.L.tsqa_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _err(self, rc):
+        return TsqError(rc, self.L.tsqa_last_error(self.h).decode())
+
+    def set_variant(self, enc: int, dec: int) -> None:
+        self.L.tsqa_set_kernel_variant(self.h, enc, dec)
+
+    def profile(self, on: bool) -> None:
+        self.L.tsqa_profile_enable(self.h, 1 if on else 0)
+
+    def profile_read(self):
+        """-> (encode_ms_sum, encode_launches, decode_ms_sum, decode_launches) since the last read."""
+        em, dm, en, dn = C.c_double(0), C.c_double(0), C.c_uint32(0), C.c_uint32(0)
+        self.L.tsqa_profile_read(self.h, C.byref(em), C.byref(en), C.byref(dm), C.byref(dn))
+        return em.value, en.value, dm.value, dn.value
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def compress(self, src, ext: int, out=None):
+        """src: uint8 CUDA tensor.  Returns a uint8 CUDA tensor view holding the .tsq container."""
+        n = src.numel()
+        if out is None:
+            out = self.torch.empty(container_bound(n), dtype=self.torch.uint8, device=self.device)
+        sz = C.c_size_t(0)
+        rc = self.L.tsqa_compress_device(self.h, src.data_ptr(), n, out.data_ptr(), out.numel(), C.byref(sz), int(ext), self._stream())
+        if rc:
+            raise self._err(rc)
+        return out[: sz.value]
+
+    def decompress(self, blob, out=None, out_cap=None):
+        n = blob.numel()
+        if out is None:
+            total = int.from_bytes(bytes(blob[8:16].cpu().numpy()), "little") if out_cap is None else out_cap
+            out = self.torch.empty(max(total, 1), dtype=self.torch.uint8, device=self.device)
+        sz = C.c_size_t(0)
+        rc = self.L.tsqa_decompress_device(self.h, blob.data_ptr(), n, out.data_ptr(), out.numel(), C.byref(sz), self._stream())
+        if rc:
+            raise self._err(rc)
+        return out[: sz.value]
+
+    # asynchronous forms: nothing is synchronised; results land in self._size / self._status
+    def compress_async(self, src, ext: int, out):
+        rc = self.L.tsqa_compress_device_async(self.h, src.data_ptr(), src.numel(), out.data_ptr(), out.numel(),
+                                               self._size.data_ptr(), self._status.data_ptr(), int(ext), self._stream())
+        if rc:
+            raise self._err(rc)
+
+    def decompress_async(self, blob, n_blocks: int, out):
+        rc = self.L.tsqa_decompress_device_async(self.h, blob.data_ptr(), blob.numel(), n_blocks, out.data_ptr(), out.numel(),
+                                                 self._size.data_ptr(), self._status.data_ptr(), self._stream())
+        if rc:
+            raise self._err(rc)
+
+    def last_size_status(self):
+        return int(self._size.item()), int(self._status.item())
+
+
+# ---------------------------------------------------------------------------
+# The reference's API over host bytes
+# ---------------------------------------------------------------------------
+
+def tsq_encode(data: bytes, ext: int) -> bytes:
+    """tsqEncode (turbosqueeze.h:657): one block (<= 4 MiB) -> block stream."""
+    L = lib()
+    n = len(data)
+    src = C.create_string_buffer(bytes(data), n)
+    dst = C.create_string_buffer(OUTPUT_SZ)
+    sz = C.c_uint32(0)
+    ctx = L.tsqAllocateContext()
+    try:
+        L.tsqInit(ctx)
+        L.tsqEncode(ctx, src, dst, C.byref(sz), n, int(ext))
+    finally:
+        L.tsqDeallocateContext(ctx)
+    if sz.value == 0:
+        raise TsqError(2, "tsqEncode produced no output (no device?)")
+    return dst.raw[: sz.value]
+
+
+def tsq_decode(stream: bytes, ext: int) -> bytes:
+    """tsqDecode (turbosqueeze.h:670): block stream -> block; b'' when *outputSize == 0."""
+    L = lib()
+    src = C.create_string_buffer(bytes(stream), len(stream))
+    dst = C.create_string_buffer(BLOCK_SZ + 256)
+    sz = C.c_uint32(0)
+    L.tsqDecode(src, dst, C.byref(sz), len(stream), int(ext))
+    return dst.raw[: sz.value]
+
+
+def _take_malloced(ptr: C.c_void_p, size: int) -> bytes:
+    try:
+        return C.string_at(ptr, size)
+    finally:
+        _libc.free(ptr)
+
+
+def tsq_compress_mt(data: bytes, ext: bool, progress=None):
+    """tsqAllocateContextCompression_MT + tsqCompress_MT (memory -> memory) + deallocate."""
+    L = lib()
+    ctx = L.tsqAllocateContextCompression_MT(False)
+    if not ctx:
+        raise TsqError(1, "tsqAllocateContextCompression_MT returned NULL")
+    try:
+        buf = C.create_string_buffer(bytes(data), len(data))
+        out, sz = C.c_void_p(), C.c_size_t(0)
+        ok = L.tsqCompress_MT(ctx, buf, len(data), False, C.byref(out), C.byref(sz), False, bool(ext), 0)
+        if not ok:
+            return None
+        return _take_malloced(out, sz.value)
+    finally:
+        L.tsqDeallocateContextCompression_MT(ctx)
+
+
+def tsq_decompress_mt(blob: bytes):
+    L = lib()
+    ctx = L.tsqAllocateContextDecompression_MT(False)
+    if not ctx:
+        raise TsqError(1, "tsqAllocateContextDecompression_MT returned NULL")
+    try:
+        buf = C.create_string_buffer(bytes(blob), len(blob))
+        out, sz = C.c_void_p(), C.c_size_t(0)
+        ok = L.tsqDecompress_MT(ctx, buf, len(blob), False, C.byref(out), C.byref(sz), False)
+        if not ok:
+            return None
+        return _take_malloced(out, sz.value)
+    finally:
+        L.tsqDeallocateContextDecompression_MT(ctx)

@@ -1,0 +1,667 @@
+// tsq_compat.hip -- the reference's public API (turbosqueeze.h:441-674) on top of the device
+// path, and the HIP stream scheduler that replaces the reference's reader/worker/writer thread
+// pool (tsq_threads.cpp).  Host code only; the data path is H2D copy -> kernels -> D2H copy.
+//
+// Scheduler shape.  A job is cut into batches of consecutive 4 MiB blocks.  Batch k runs on
+// pipeline lane k % L; a lane owns one tsqa_ctx (HIP stream + HBM scratch), pinned host staging
+// buffers and device staging buffers.  Lanes are spread round-robin over the devices listed in
+// TSQ_AMD_DEVICES (default: the current device), so with 8 devices consecutive batches go to
+// consecutive GPUs and the host gathers the compressed pieces in block order -- the analogue
+// of block i -> worker i % num_cores (tsq_threads.cpp:71,463) and of the ordered writer
+// (tsq_threads.cpp:192-275, 604-676).  While lane A computes, the scheduler thread drains the
+// oldest lane (D2H + append + progress callbacks) and stages the next batch.
+#include "tsq_internal.h"
+#include "tsq_common.cuh"
+
+#include "../../include/turbosqueeze.h"
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+using tsq::FrameInfo;
+using tsq::kBlockSize;
+using tsq::kSlotSize;
+
+namespace {
+
+constexpr size_t kHalo = 128;   // look-ahead the encoder may read past a block
+
+std::vector<int> device_list()
+{
+    std::vector<int> devs;
+    if (const char* env = getenv("TSQ_AMD_DEVICES")) {
+        const char* p = env;
+        while (*p) {
+            char* end = nullptr;
+            long v = strtol(p, &end, 10);
+            if (end == p) break;
+            devs.push_back((int)v);
+            p = (*end == ',') ? end + 1 : end;
+        }
+    }
+    if (devs.empty()) {
+        int d = 0;
+        if (const char* env = getenv("TSQ_AMD_DEVICE")) d = atoi(env);
+        else if (hipGetDevice(&d) != hipSuccess) d = 0;
+        devs.push_back(d);
+    }
+    return devs;
+}
+
+size_t env_size(const char* name, size_t dflt)
+{
+    const char* e = getenv(name);
+    if (!e) return dflt;
+    long v = atol(e);
+    return v > 0 ? (size_t)v : dflt;
+}
+
+void complain_once(const char* what)
+{
+    static std::atomic<bool> said{false};
+    if (!said.exchange(true))
+        fprintf(stderr, "turbosqueeze_amd: %s -- there is no CPU fallback, the call fails\n", what);
+}
+
+// ---- sequential byte source / sink over memory or FILE* ----
+struct Source {
+    const uint8_t* mem = nullptr; size_t size = 0; FILE* f = nullptr; bool own = false;
+    bool open(const uint8_t* in, size_t szin, bool infile) {
+        if (infile) {
+            f = fopen(reinterpret_cast<const char*>(in), "rb");          // tsq_threads.cpp:294-310
+            if (!f) return false;
+            own = true;
+            fseek(f, 0, SEEK_END); long s = ftell(f); fseek(f, 0, SEEK_SET);
+            if (s < 0) return false;
+            size = (size_t)s;
+        } else { mem = in; size = szin; }
+        return true;
+    }
+    // read [at, at+len) into dst; returns bytes obtained
+    size_t read_at(size_t at, size_t len, uint8_t* dst) {
+        if (at >= size) return 0;
+        if (len > size - at) len = size - at;
+        if (mem) { memcpy(dst, mem + at, len); return len; }
+        if (fseek(f, (long)at, SEEK_SET) != 0) return 0;
+        return fread(dst, 1, len, f);
+    }
+    ~Source() { if (own && f) fclose(f); }
+};
+
+struct Sink {
+    uint8_t* mem = nullptr; size_t cap = 0, at = 0; FILE* f = nullptr; bool own = false; bool failed = false;
+    bool open_file(const char* path) { f = fopen(path, "wb"); own = true; return f != nullptr; }
+    bool open_mem(size_t capacity) { mem = static_cast<uint8_t*>(malloc(capacity ? capacity : 1)); cap = capacity; return mem != nullptr; }
+    void write(const uint8_t* p, size_t n) {
+        if (f) { if (fwrite(p, 1, n, f) != n) failed = true; }
+        else if (at + n <= cap) memcpy(mem + at, p, n);
+        else failed = true;
+        at += n;
+    }
+    ~Sink() { if (own && f) fclose(f); }
+};
+
+// ---- one pipeline lane ----
+struct Lane {
+    tsqa_ctx* dev = nullptr;
+    uint8_t *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
+    FrameInfo* h_frames = nullptr;
+    size_t in_cap = 0, out_cap = 0, frames_cap = 0;
+    uint64_t* h_size = nullptr; int32_t* h_status = nullptr;   // pinned result words
+    hipEvent_t ev = nullptr;
+
+    bool init(int device) {
+        if (tsqa_create(device, &dev) != TSQA_OK) return false;
+        if (hipHostMalloc(&h_size, sizeof(uint64_t), hipHostMallocPortable) != hipSuccess) return false;
+        if (hipHostMalloc(&h_status, sizeof(int32_t), hipHostMallocPortable) != hipSuccess) return false;
+        return hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+    }
+    bool reserve(size_t in_bytes, size_t out_bytes, size_t n_frames) {
+        (void)hipSetDevice(dev->device);
+        if (in_bytes > in_cap) {
+            (void)hipHostFree(h_in); (void)hipFree(d_in); h_in = d_in = nullptr; in_cap = 0;
+            if (hipHostMalloc(&h_in, in_bytes, hipHostMallocPortable) != hipSuccess) return false;
+            if (hipMalloc(&d_in, in_bytes) != hipSuccess) return false;
+            in_cap = in_bytes;
+        }
+        if (out_bytes > out_cap) {
+            (void)hipHostFree(h_out); (void)hipFree(d_out); h_out = d_out = nullptr; out_cap = 0;
+            if (hipHostMalloc(&h_out, out_bytes, hipHostMallocPortable) != hipSuccess) return false;
+            if (hipMalloc(&d_out, out_bytes) != hipSuccess) return false;
+            out_cap = out_bytes;
+        }
+        if (n_frames > frames_cap) {
+            (void)hipHostFree(h_frames); h_frames = nullptr; frames_cap = 0;
+            if (hipHostMalloc(&h_frames, n_frames * sizeof(FrameInfo), hipHostMallocPortable) != hipSuccess) return false;
+            frames_cap = n_frames;
+        }
+        return true;
+    }
+    void destroy() {
+        if (dev) (void)hipSetDevice(dev->device);
+        if (ev) (void)hipEventDestroy(ev);
+        (void)hipHostFree(h_in); (void)hipHostFree(h_out); (void)hipHostFree(h_frames);
+        (void)hipHostFree(h_size); (void)hipHostFree(h_status);
+        (void)hipFree(d_in); (void)hipFree(d_out);
+        tsqa_destroy(dev);
+        dev = nullptr;
+    }
+};
+
+struct Job {
+    uint8_t* in = nullptr; size_t szin = 0; bool infile = false;
+    uint8_t** out = nullptr; size_t* szout = nullptr; bool outfile = false;
+    std::string out_path;
+    bool ext = false;
+    uint32_t id = 0;
+    std::function<void(uint32_t, bool)> done;
+    std::function<void(uint32_t, double)> progress;
+};
+
+struct InFlight { size_t lane; uint32_t first_block, n_blocks; size_t out_bytes; };
+
+class Scheduler {
+public:
+    explicit Scheduler(bool compress, bool verbose) : compress_(compress), verbose_(verbose) {}
+
+    bool start() {
+        std::vector<int> devs = device_list();
+        size_t per_dev = env_size("TSQ_AMD_LANES", 2);
+        for (size_t k = 0; k < per_dev * devs.size(); ++k) {
+            Lane l;
+            if (!l.init(devs[k % devs.size()])) { l.destroy(); for (auto& x : lanes_) x.destroy(); lanes_.clear(); return false; }
+            lanes_.push_back(l);
+        }
+        batch_blocks_ = (uint32_t)env_size("TSQ_AMD_BATCH_BLOCKS", 16);
+        thread_ = std::thread([this] { loop(); });
+        return true;
+    }
+    uint32_t n_cus() const { return lanes_.empty() ? 0 : (uint32_t)lanes_[0].dev->n_cus; }
+
+    uint32_t submit(Job&& j) {
+        std::lock_guard<std::mutex> g(m_);
+        j.id = next_id_++;
+        uint32_t id = j.id;
+        inflight_++;
+        q_.push_back(std::move(j));
+        cv_.notify_all();
+        return id;
+    }
+    // tsq_context.cpp:150-155: deallocation waits for every queued job, then joins.
+    void stop() {
+        {
+            std::unique_lock<std::mutex> g(m_);
+            idle_cv_.wait(g, [this] { return inflight_ == 0; });
+            exit_ = true;
+            cv_.notify_all();
+        }
+        if (thread_.joinable()) thread_.join();
+        for (auto& l : lanes_) l.destroy();
+        lanes_.clear();
+    }
+
+private:
+    void loop() {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [this] { return exit_ || !q_.empty(); });
+                if (q_.empty()) return;
+                j = std::move(q_.front());
+                q_.pop_front();
+            }
+            bool ok = compress_ ? run_compress(j) : run_decompress(j);
+            if (verbose_) printf("turbosqueeze_amd: job %u %s\n", j.id, ok ? "completed" : "FAILED");
+            if (j.done) j.done(j.id, ok);                       // tsq_threads.cpp:256-262,657-663
+            {
+                std::lock_guard<std::mutex> g(m_);
+                inflight_--;
+                idle_cv_.notify_all();
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ compression
+    bool run_compress(Job& j) {
+        Source src;
+        if (!src.open(j.in, j.szin, j.infile) || src.size == 0) return false;
+        const size_t total = src.size;
+        const uint32_t nb = (uint32_t)tsqa_block_count(total);       // tsq_threads.cpp:313
+        Sink sink;
+        if (j.outfile) { if (!sink.open_file(j.out_path.c_str())) return false; }
+        else if (!sink.open_mem(tsqa_container_bound(total))) return false;   // tsq_threads.cpp:339
+
+        uint8_t header[16];                                          // tsq_threads.cpp:333-335,355-359
+        memcpy(header, "TSQ1", 4); memcpy(header + 4, &nb, 4);
+        uint64_t t64 = total; memcpy(header + 8, &t64, 8);
+        sink.write(header, 16);
+
+        bool ok = true;
+        std::deque<InFlight> fly;
+        uint32_t done_blocks = 0;
+        auto drain_one = [&]() {
+            InFlight f = fly.front(); fly.pop_front();
+            Lane& l = lanes_[f.lane];
+            (void)hipSetDevice(l.dev->device);
+            if (hipEventSynchronize(l.ev) != hipSuccess || *l.h_status != 0) { ok = false; return; }
+            size_t sz = (size_t)*l.h_size;                            // batch container: 16-byte header + frames
+            if (sz < 16 || sz > l.out_cap) { ok = false; return; }
+            if (hipMemcpyAsync(l.h_out, l.d_out + 16, sz - 16, hipMemcpyDeviceToHost, l.dev->stream) != hipSuccess ||
+                hipStreamSynchronize(l.dev->stream) != hipSuccess) { ok = false; return; }
+            sink.write(l.h_out, sz - 16);
+            for (uint32_t b = 0; b < f.n_blocks; ++b) {               // tsq_threads.cpp:248-254
+                done_blocks++;
+                if (j.progress) j.progress(j.id, (double)done_blocks / (double)nb);
+            }
+        };
+
+        for (uint32_t b0 = 0, k = 0; b0 < nb && ok; b0 += batch_blocks_, ++k) {
+            const uint32_t bn = nb - b0 < batch_blocks_ ? nb - b0 : batch_blocks_;
+            const size_t lane_i = k % lanes_.size();
+            while (ok && fly.size() >= lanes_.size()) drain_one();
+            if (!ok) break;
+            Lane& l = lanes_[lane_i];
+            const size_t at = (size_t)b0 * kBlockSize;
+            const size_t want = (size_t)bn * kBlockSize;
+            const size_t n = total - at < want ? total - at : want;
+            if (!l.reserve(want + kHalo, tsqa_container_bound(want), 0)) { ok = false; break; }
+            // the batch plus the first bytes of the next one: block k's look-ahead reads block k+1
+            size_t got = src.read_at(at, n + kHalo, l.h_in);
+            if (got < n) { ok = false; break; }
+            (void)hipSetDevice(l.dev->device);
+            hipStream_t s = l.dev->stream;
+            if (hipMemcpyAsync(l.d_in, l.h_in, got, hipMemcpyHostToDevice, s) != hipSuccess) { ok = false; break; }
+            if (hipMemsetAsync(l.dev->d_status, 0, sizeof(int32_t), s) != hipSuccess) { ok = false; break; }
+            if (l.dev->launch_encode(l.d_in, n, got, j.ext ? 1u : 0u, l.dev->d_status, s) != TSQA_OK) { ok = false; break; }
+            if (l.dev->launch_pack(n, j.ext ? 1u : 0u, l.d_out, l.out_cap, l.dev->d_size, l.dev->d_status, s) != TSQA_OK) { ok = false; break; }
+            (void)hipMemcpyAsync(l.h_size, l.dev->d_size, sizeof(uint64_t), hipMemcpyDeviceToHost, s);
+            (void)hipMemcpyAsync(l.h_status, l.dev->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+            if (hipEventRecord(l.ev, s) != hipSuccess) { ok = false; break; }
+            fly.push_back({lane_i, b0, bn, 0});
+        }
+        while (ok && !fly.empty()) drain_one();
+        for (auto& l : lanes_) { (void)hipSetDevice(l.dev->device); (void)hipStreamSynchronize(l.dev->stream); }
+        if (sink.failed) ok = false;
+        if (!j.outfile) {
+            if (ok) { *j.out = sink.mem; *j.szout = sink.at; }       // tsq_threads.cpp:375-379; caller free()s
+            else { free(sink.mem); }
+        }
+        return ok;
+    }
+
+    // ------------------------------------------------------------------ decompression
+    bool run_decompress(Job& j) {
+        Source src;
+        if (!src.open(j.in, j.szin, j.infile)) return false;
+        uint8_t header[16];
+        if (src.read_at(0, 16, header) != 16 || memcmp(header, "TSQ1", 4) != 0) return false;   // tsq_threads.cpp:732-752
+        uint32_t nb; uint64_t total;
+        memcpy(&nb, header + 4, 4); memcpy(&total, header + 8, 8);
+        if (nb == 0) return false;                                                             // tsq_threads.cpp:759-768
+        if ((uint64_t)nb * kBlockSize < total) return false;
+        Sink sink;
+        if (j.outfile) { if (!sink.open_file(j.out_path.c_str())) return false; }
+        else if (!sink.open_mem((size_t)total + 128)) return false;                            // tsq_threads.cpp:795
+
+        bool ok = true;
+        std::deque<InFlight> fly;
+        uint32_t done_blocks = 0;
+        auto drain_one = [&]() {
+            InFlight f = fly.front(); fly.pop_front();
+            Lane& l = lanes_[f.lane];
+            (void)hipSetDevice(l.dev->device);
+            if (hipEventSynchronize(l.ev) != hipSuccess || *l.h_status != 0) { ok = false; return; }
+            sink.write(l.h_out, f.out_bytes);
+            for (uint32_t b = 0; b < f.n_blocks; ++b) {                // tsq_threads.cpp:654-655
+                done_blocks++;
+                if (j.progress) j.progress(j.id, (double)done_blocks / (double)nb);
+            }
+        };
+
+        size_t at = 16;                       // container cursor: the frame walk is serial (tsq_threads.cpp:513-524)
+        uint64_t produced = 0;
+        const size_t in_budget = (size_t)batch_blocks_ * (3 + kSlotSize);
+        for (uint32_t b0 = 0, k = 0; b0 < nb && ok; ++k) {
+            const size_t lane_i = k % lanes_.size();
+            while (ok && fly.size() >= lanes_.size()) drain_one();
+            if (!ok) break;
+            Lane& l = lanes_[lane_i];
+            if (!l.reserve(in_budget + 16, (size_t)batch_blocks_ * kBlockSize + 256, batch_blocks_)) { ok = false; break; }
+            // gather whole frames into the staging buffer until the batch is full
+            size_t cur = 0; uint32_t bn = 0; size_t out_bytes = 0;
+            while (b0 + bn < nb && bn < batch_blocks_) {
+                uint8_t fh[3];
+                if (src.read_at(at + cur, 3, fh) != 3) break;
+                uint32_t frame = (uint32_t)fh[0] | ((uint32_t)fh[1] << 8) | ((uint32_t)fh[2] << 16);
+                uint32_t len = frame & 0x7FFFFFu;                                             // tsq_threads.cpp:513-517
+                if (len < 3 || len > kSlotSize) { ok = false; break; }                         // tsq_threads.cpp:526-531
+                if (cur + 3 + len > l.in_cap) break;
+                memcpy(l.h_in + cur, fh, 3);
+                if (src.read_at(at + cur + 3, len, l.h_in + cur + 3) != len) { ok = false; break; }
+                uint32_t usize = (uint32_t)l.h_in[cur + 3] | ((uint32_t)l.h_in[cur + 4] << 8) | ((uint32_t)l.h_in[cur + 5] << 16);
+                if (usize > kBlockSize || produced + out_bytes + usize > total) { ok = false; break; }
+                FrameInfo& fi = l.h_frames[bn];
+                fi.stream_at = cur + 3; fi.out_at = out_bytes; fi.stream_len = len; fi.ext = frame >> 23; fi.out_len = usize; fi.pad = 0;
+                out_bytes += usize; cur += 3 + len; bn++;
+            }
+            if (!ok) break;
+            if (bn == 0) { ok = false; break; }                        // truncated container
+            (void)hipSetDevice(l.dev->device);
+            hipStream_t s = l.dev->stream;
+            if (l.dev->reserve(bn, false) != TSQA_OK) { ok = false; break; }
+            if (hipMemcpyAsync(l.d_in, l.h_in, cur, hipMemcpyHostToDevice, s) != hipSuccess) { ok = false; break; }
+            if (hipMemcpyAsync(l.dev->frames, l.h_frames, bn * sizeof(FrameInfo), hipMemcpyHostToDevice, s) != hipSuccess) { ok = false; break; }
+            if (hipMemsetAsync(l.dev->d_status, 0, sizeof(int32_t), s) != hipSuccess) { ok = false; break; }
+            if (l.dev->launch_decode(l.d_in, bn, l.d_out, l.dev->d_status, s) != TSQA_OK) { ok = false; break; }
+            (void)hipMemcpyAsync(l.h_out, l.d_out, out_bytes, hipMemcpyDeviceToHost, s);
+            (void)hipMemcpyAsync(l.h_status, l.dev->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+            if (hipEventRecord(l.ev, s) != hipSuccess) { ok = false; break; }
+            fly.push_back({lane_i, b0, bn, out_bytes});
+            produced += out_bytes; at += cur; b0 += bn;
+        }
+        while (ok && !fly.empty()) drain_one();
+        for (auto& l : lanes_) { (void)hipSetDevice(l.dev->device); (void)hipStreamSynchronize(l.dev->stream); }
+        if (ok && produced != total) ok = false;
+        if (sink.failed) ok = false;
+        if (!j.outfile) {
+            if (ok) { *j.out = sink.mem; *j.szout = (size_t)total; }
+            else { free(sink.mem); }
+        }
+        return ok;
+    }
+
+    const bool compress_, verbose_;
+    std::vector<Lane> lanes_;
+    uint32_t batch_blocks_ = 16;
+    std::thread thread_;
+    std::mutex m_;
+    std::condition_variable cv_, idle_cv_;
+    std::deque<Job> q_;
+    uint32_t next_id_ = 1;          // turbosqueeze.h: maxjobid starts at 1
+    int inflight_ = 0;
+    bool exit_ = false;
+};
+
+Scheduler* make_scheduler(bool compress, bool verbose)
+{
+    Scheduler* s = new Scheduler(compress, verbose);
+    if (!s->start()) {
+        complain_once("no usable gfx950 device (or HIP initialisation failed)");
+        delete s;
+        return nullptr;
+    }
+    return s;
+}
+
+uint32_t submit_job(Scheduler* s, uint8_t* in, size_t szin, bool infile, uint8_t** out, size_t* szout, bool outfile,
+                    bool ext, std::function<void(uint32_t, bool)> done, std::function<void(uint32_t, double)> progress)
+{
+    // tsq_threads.cpp:296-306,415-418: argument failures report through the callback with job id 0
+    if (!s || !in || !out || (!outfile && !szout) || (!infile && szin == 0) || (outfile && !*out)) {
+        if (done) done(0, false);
+        return 0;
+    }
+    Job j;
+    j.in = in; j.szin = szin; j.infile = infile; j.out = out; j.szout = szout; j.outfile = outfile; j.ext = ext;
+    if (outfile) j.out_path = reinterpret_cast<const char*>(*out);
+    j.done = std::move(done); j.progress = std::move(progress);
+    return s->submit(std::move(j));
+}
+
+bool run_sync(Scheduler* s, uint8_t* in, size_t szin, bool infile, uint8_t** out, size_t* szout, bool outfile, bool ext)
+{
+    if (!s || !in || !out || (!infile && szin == 0)) return false;     // tsq_threads.cpp:415-418
+    std::mutex m; std::condition_variable cv; bool finished = false, result = false;
+    uint32_t id = submit_job(s, in, szin, infile, out, szout, outfile, ext,
+                             [&](uint32_t, bool ok) { std::lock_guard<std::mutex> g(m); result = ok; finished = true; cv.notify_all(); },
+                             nullptr);
+    if (id == 0) return false;
+    std::unique_lock<std::mutex> g(m);                                 // tsq_threads.cpp:435-438
+    cv.wait(g, [&] { return finished; });
+    return result;
+}
+
+// ---- single-block codec used by tsqEncode / tsqDecode ----
+struct BlockCodec {
+    std::mutex m;
+    Lane lane;
+    bool tried = false, ready = false;
+    bool ensure() {
+        if (tried) return ready;
+        tried = true;
+        ready = lane.init(device_list()[0]) && lane.reserve(kBlockSize + kHalo + kSlotSize, kSlotSize + 256, 1);
+        if (!ready) { complain_once("no usable gfx950 device (or HIP initialisation failed)"); }
+        return ready;
+    }
+};
+BlockCodec& block_codec() { static BlockCodec* c = new BlockCodec(); return *c; }
+
+}  // namespace
+
+// =============================================================================================
+// extern "C" -- the reference's names
+// =============================================================================================
+
+extern "C" struct TSQCompressionContext* tsqAllocateContext(void)
+{
+    // tsq_context.cpp:56-74: a 128-byte aligned 256 KiB table the caller may touch
+    auto* c = static_cast<TSQCompressionContext*>(malloc(sizeof(TSQCompressionContext)));
+    if (!c) return nullptr;
+    c->refhash = static_cast<uint16_t*>(aligned_alloc(128, TSQ_HASH_SZ));
+    if (!c->refhash) { free(c); return nullptr; }
+    return c;
+}
+
+extern "C" void tsqDeallocateContext(struct TSQCompressionContext* ctx)
+{
+    if (!ctx) return;
+    free(ctx->refhash);
+    free(ctx);
+}
+
+extern "C" void tsqInit(struct TSQCompressionContext* ctx)
+{
+    if (ctx && ctx->refhash) memset(ctx->refhash, 0, TSQ_HASH_SZ);    // tsq_context.cpp:77-80
+}
+
+extern "C" void tsqEncode(struct TSQCompressionContext* ctx, uint8_t* inputBlock, uint8_t* outputBlock,
+                          uint32_t* outputSize, uint32_t inputSize, uint32_t withExtensions)
+{
+    (void)ctx;   // the device kernel zeroes and owns its table; the host table is API compatibility only
+    if (outputSize) *outputSize = 0;
+    if (!inputBlock || !outputBlock || !outputSize || inputSize == 0 || inputSize > kBlockSize) return;
+    BlockCodec& bc = block_codec();
+    std::lock_guard<std::mutex> g(bc.m);
+    if (!bc.ensure()) return;
+    Lane& l = bc.lane;
+    (void)hipSetDevice(l.dev->device);
+    hipStream_t s = l.dev->stream;
+    memcpy(l.h_in, inputBlock, inputSize);
+    if (hipMemcpyAsync(l.d_in, l.h_in, inputSize, hipMemcpyHostToDevice, s) != hipSuccess) return;
+    (void)hipMemsetAsync(l.dev->d_status, 0, sizeof(int32_t), s);
+    if (l.dev->launch_encode(l.d_in, inputSize, inputSize, withExtensions, l.dev->d_status, s) != TSQA_OK) return;
+    *l.h_size = 0;
+    (void)hipMemcpyAsync(l.h_size, l.dev->sizes, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(l.h_status, l.dev->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    if (hipStreamSynchronize(s) != hipSuccess || *l.h_status != 0) return;
+    uint32_t sz = (uint32_t)(*l.h_size & 0xFFFFFFFFu);
+    if (sz > kSlotSize) return;
+    if (hipMemcpyAsync(l.h_out, l.dev->slots, sz, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return;
+    memcpy(outputBlock, l.h_out, sz);
+    *outputSize = sz;
+}
+
+extern "C" void tsqDecode(uint8_t* inputBlock, uint8_t* outputBlock, uint32_t* outputSize, uint32_t inputSize,
+                          uint32_t withExtensions)
+{
+    if (outputSize) *outputSize = 0;
+    if (!inputBlock || !outputBlock || !outputSize || inputSize < 3 || inputSize > kSlotSize) return;
+    uint32_t usize = (uint32_t)inputBlock[0] | ((uint32_t)inputBlock[1] << 8) | ((uint32_t)inputBlock[2] << 16);
+    if (usize > kBlockSize) return;                                    // tsq_decode.cpp:53,146
+    BlockCodec& bc = block_codec();
+    std::lock_guard<std::mutex> g(bc.m);
+    if (!bc.ensure()) return;
+    Lane& l = bc.lane;
+    (void)hipSetDevice(l.dev->device);
+    hipStream_t s = l.dev->stream;
+    if (l.dev->reserve(1, false) != TSQA_OK) return;
+    memcpy(l.h_in, inputBlock, inputSize);
+    FrameInfo& fi = l.h_frames[0];
+    fi.stream_at = 0; fi.out_at = 0; fi.stream_len = inputSize; fi.ext = withExtensions ? 1u : 0u; fi.out_len = usize; fi.pad = 0;
+    if (hipMemcpyAsync(l.d_in, l.h_in, inputSize, hipMemcpyHostToDevice, s) != hipSuccess) return;
+    (void)hipMemcpyAsync(l.dev->frames, l.h_frames, sizeof(FrameInfo), hipMemcpyHostToDevice, s);
+    (void)hipMemsetAsync(l.dev->d_status, 0, sizeof(int32_t), s);
+    if (l.dev->launch_decode(l.d_in, 1, l.d_out, l.dev->d_status, s) != TSQA_OK) return;
+    (void)hipMemcpyAsync(l.h_out, l.d_out, usize, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(l.h_status, l.dev->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    if (hipStreamSynchronize(s) != hipSuccess || *l.h_status != 0) return;
+    memcpy(outputBlock, l.h_out, usize);
+    *outputSize = usize;
+}
+
+// ---- _MT contexts ----
+
+extern "C" struct TSQCompressionContext_MT* tsqAllocateContextCompression_MT(bool verbose)
+{
+    Scheduler* s = make_scheduler(true, verbose);
+    if (!s) return nullptr;
+    auto* c = new TSQCompressionContext_MT{s->n_cus(), s};
+    return c;
+}
+
+extern "C" void tsqDeallocateContextCompression_MT(struct TSQCompressionContext_MT* ctx)
+{
+    if (!ctx) return;
+    auto* s = static_cast<Scheduler*>(ctx->impl);
+    s->stop();
+    delete s;
+    delete ctx;
+}
+
+extern "C" struct TSQDecompressionContext_MT* tsqAllocateContextDecompression_MT(bool verbose)
+{
+    Scheduler* s = make_scheduler(false, verbose);
+    if (!s) return nullptr;
+    auto* c = new TSQDecompressionContext_MT{s->n_cus(), s};
+    return c;
+}
+
+extern "C" void tsqDeallocateContextDecompression_MT(struct TSQDecompressionContext_MT* ctx)
+{
+    if (!ctx) return;
+    auto* s = static_cast<Scheduler*>(ctx->impl);
+    s->stop();
+    delete s;
+    delete ctx;
+}
+
+extern "C" bool tsqCompress_MT(struct TSQCompressionContext_MT* ctx, uint8_t* in, size_t szin, bool infile, uint8_t** out,
+                               size_t* szout, bool outfile, bool useextensions, uint32_t level)
+{
+    (void)level;                                                       // ignored, as tsq_threads.cpp:98
+    if (!ctx) return false;
+    return run_sync(static_cast<Scheduler*>(ctx->impl), in, szin, infile, out, szout, outfile, useextensions);
+}
+
+extern "C" bool tsqDecompress_MT(struct TSQDecompressionContext_MT* ctx, uint8_t* in, size_t szin, bool infile, uint8_t** out,
+                                 size_t* szout, bool outfile)
+{
+    if (!ctx) return false;
+    return run_sync(static_cast<Scheduler*>(ctx->impl), in, szin, infile, out, szout, outfile, false);
+}
+
+extern "C" uint32_t tsqCompressAsync_MT(TSQCompressionContext_MT* ctx, uint8_t* in, size_t szin, bool infile, uint8_t** out,
+                                        size_t* szout, bool outfile, bool useextensions, uint32_t level,
+                                        std::function<void(uint32_t, bool)> done, std::function<void(uint32_t, double)> progress)
+{
+    (void)level;
+    return submit_job(ctx ? static_cast<Scheduler*>(ctx->impl) : nullptr, in, szin, infile, out, szout, outfile, useextensions,
+                      std::move(done), std::move(progress));
+}
+
+extern "C" uint32_t tsqDecompressAsync_MT(TSQDecompressionContext_MT* ctx, uint8_t* in, size_t szin, bool infile, uint8_t** out,
+                                          size_t* szout, bool outfile, std::function<void(uint32_t, bool)> done,
+                                          std::function<void(uint32_t, double)> progress)
+{
+    return submit_job(ctx ? static_cast<Scheduler*>(ctx->impl) : nullptr, in, szin, infile, out, szout, outfile, false,
+                      std::move(done), std::move(progress));
+}
+
+extern "C" uint32_t tsqa_compress_async_cb(struct TSQCompressionContext_MT* ctx, uint8_t* in, size_t szin, bool infile, uint8_t** out,
+                                           size_t* szout, bool outfile, bool useextensions, uint32_t level, tsqa_done_fn done,
+                                           tsqa_progress_fn progress, void* user)
+{
+    std::function<void(uint32_t, bool)> d;
+    std::function<void(uint32_t, double)> p;
+    if (done) d = [done, user](uint32_t id, bool ok) { done(id, ok, user); };
+    if (progress) p = [progress, user](uint32_t id, double f) { progress(id, f, user); };
+    return tsqCompressAsync_MT(ctx, in, szin, infile, out, szout, outfile, useextensions, level, std::move(d), std::move(p));
+}
+
+extern "C" uint32_t tsqa_decompress_async_cb(struct TSQDecompressionContext_MT* ctx, uint8_t* in, size_t szin, bool infile,
+                                             uint8_t** out, size_t* szout, bool outfile, tsqa_done_fn done,
+                                             tsqa_progress_fn progress, void* user)
+{
+    std::function<void(uint32_t, bool)> d;
+    std::function<void(uint32_t, double)> p;
+    if (done) d = [done, user](uint32_t id, bool ok) { done(id, ok, user); };
+    if (progress) p = [progress, user](uint32_t id, double f) { progress(id, f, user); };
+    return tsqDecompressAsync_MT(ctx, in, szin, infile, out, szout, outfile, std::move(d), std::move(p));
+}
+
+// ---- FILE* to FILE* (turbosqueeze.cpp:48-147): same scheduler, streams supplied by the caller ----
+
+namespace {
+bool slurp(FILE* f, std::vector<uint8_t>& buf)
+{
+    if (!f) return false;
+    fseek(f, 0, SEEK_END); long s = ftell(f); fseek(f, 0, SEEK_SET);
+    if (s < 0) return false;
+    buf.resize((size_t)s);
+    return s == 0 || fread(buf.data(), 1, (size_t)s, f) == (size_t)s;
+}
+}  // namespace
+
+extern "C" void tsqCompress(FILE* in, FILE* out, bool useextensions, uint32_t level)
+{
+    (void)level;                                                       // turbosqueeze.cpp:48
+    std::vector<uint8_t> buf;
+    if (!out || !slurp(in, buf)) return;
+    if (buf.empty()) {                                                 // header only, as turbosqueeze.cpp:64-67 with n_blocks = 0
+        uint8_t header[16] = {'T', 'S', 'Q', '1'};
+        fwrite(header, 1, 16, out);
+        return;
+    }
+    TSQCompressionContext_MT* ctx = tsqAllocateContextCompression_MT(false);
+    if (!ctx) return;
+    uint8_t* blob = nullptr; size_t sz = 0;
+    if (tsqCompress_MT(ctx, buf.data(), buf.size(), false, &blob, &sz, false, useextensions, 0)) {
+        fwrite(blob, 1, sz, out);
+        free(blob);
+    }
+    tsqDeallocateContextCompression_MT(ctx);
+}
+
+extern "C" void tsqDecompress(FILE* in, FILE* out)
+{
+    std::vector<uint8_t> buf;
+    if (!out || !slurp(in, buf) || buf.size() < 16) return;            // turbosqueeze.cpp:106-117: silent return
+    TSQDecompressionContext_MT* ctx = tsqAllocateContextDecompression_MT(false);
+    if (!ctx) return;
+    uint8_t* blob = nullptr; size_t sz = 0;
+    if (tsqDecompress_MT(ctx, buf.data(), buf.size(), false, &blob, &sz, false)) {
+        fwrite(blob, 1, sz, out);
+        free(blob);
+    }
+    tsqDeallocateContextDecompression_MT(ctx);
+}

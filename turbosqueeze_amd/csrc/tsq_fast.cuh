@@ -1,0 +1,28 @@
+// tsq_fast.cuh -- the production encode/decode kernels (variant 0).
+#pragma once
+
+#include "tsq_common.cuh"
+#include "tsq_emit.cuh"
+#include "tsq_internal.h"
+#include "tsq_serial.cuh"
+
+namespace tsq {
+
+// Until the wave-parallel kernels land these forward to the serial kernels.
+inline int launch_encode_fast(tsqa_ctx* c, const uint8_t* in, size_t n, size_t readable, uint32_t ext, int32_t* status, hipStream_t s)
+{
+    const uint32_t nb = (uint32_t)((n + kBlockSize - 1) / kBlockSize);
+    int rc = c->reserve(nb, true);
+    if (rc) return rc;
+    if (ext) hipLaunchKernelGGL(enc_serial_kernel<true>, dim3(nb), dim3(64), 0, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
+    else     hipLaunchKernelGGL(enc_serial_kernel<false>, dim3(nb), dim3(64), 0, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
+    return 0;
+}
+
+inline int launch_decode_fast(tsqa_ctx* c, const uint8_t* container, uint32_t n_blocks, uint8_t* out, int32_t* status, hipStream_t s)
+{
+    hipLaunchKernelGGL(dec_serial_kernel, dim3(n_blocks), dim3(64), 0, s, container, c->frames, out, status);
+    return 0;
+}
+
+}  // namespace tsq

@@ -1,0 +1,41 @@
+// tsq_internal.h -- host-side context shared by the runtime and the reference-API layer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <utility>
+#include <vector>
+
+#include "../../include/turbosqueeze_amd.h"
+
+namespace tsq { struct FrameInfo; }
+
+struct tsqa_ctx {
+    int device = 0;
+    int n_cus = 0;
+    hipStream_t stream = nullptr;
+    // scratch in HBM
+    uint8_t* slots = nullptr;          // n_blocks x TSQ_OUTPUT_SZ encoded block streams
+    uint32_t* sizes = nullptr;         // n_blocks stream sizes
+    uint64_t* frame_at = nullptr;      // n_blocks + 1 frame offsets in the container
+    tsq::FrameInfo* frames = nullptr;  // n_blocks frame descriptors (decode)
+    uint16_t* tables = nullptr;        // n_blocks x 2^17 u16 (serial encoder variant only)
+    size_t cap_blocks = 0, cap_tables = 0;
+    uint64_t* d_size = nullptr;        // result words of the synchronous entry points
+    int32_t* d_status = nullptr;
+    int enc_variant = 0, dec_variant = 0;
+    char err[256] = {0};
+    // optional kernel timing (tsqa_profile_*): event pairs around the dominant kernels
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> enc_events, dec_events;
+    hipEvent_t prof_begin(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, hipStream_t s);
+    void prof_end(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, hipStream_t s);
+
+    void set_error(const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+    int reserve(size_t n_blocks, bool want_tables);
+    // `readable` >= n: bytes of d_in that may be read (look-ahead halo); zeros are seen beyond it
+    int launch_encode(const void* d_in, size_t n, size_t readable, uint32_t ext, int32_t* status, hipStream_t s);
+    int launch_pack(size_t n, uint32_t ext, void* d_out, size_t out_cap, uint64_t* d_out_size, int32_t* status, hipStream_t s);
+    int launch_decode(const void* d_container, uint32_t n_blocks, void* d_out, int32_t* status, hipStream_t s);
+};
