@@ -5,6 +5,7 @@
 #include "tsq_emit.cuh"
 #include "tsq_internal.h"
 #include "tsq_serial.cuh"
+#include "tsq_dec_fast.cuh"
 
 namespace tsq {
 
@@ -21,7 +22,13 @@ inline int launch_encode_fast(tsqa_ctx* c, const uint8_t* in, size_t n, size_t r
 
 inline int launch_decode_fast(tsqa_ctx* c, const uint8_t* container, uint32_t n_blocks, uint8_t* out, int32_t* status, hipStream_t s)
 {
-    hipLaunchKernelGGL(dec_serial_kernel, dim3(n_blocks), dim3(64), 0, s, container, c->frames, out, status);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)DecLds::total) != hipSuccess) { c->set_error("cannot reserve %u B of LDS", DecLds::total); return TSQA_ERR_HIP; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(dec_fast_kernel, dim3(n_blocks), dim3(DecCfg::T), DecLds::total, s, container, c->frames, out, status);
     return 0;
 }
 
