@@ -70,6 +70,17 @@ struct DecLds {
 static_assert(8 * DecCfg::MAXG * sizeof(DecSym) <= 6 * DecCfg::S, "symbol records must fit the dead tables");
 static_assert(DecLds::total <= 160 * 1024, "LDS budget");
 
+#ifdef TSQ_STATS
+__device__ unsigned long long g_dec_stats[16];
+#define TSQD_T0() unsigned long long t0_ = __builtin_amdgcn_s_memtime()
+#define TSQD_ACC(slot) do { unsigned long long t1_ = __builtin_amdgcn_s_memtime(); st_[slot] += t1_ - t0_; t0_ = t1_; } while (0)
+#define TSQD_CNT(slot, v) st_[slot] += (v)
+#else
+#define TSQD_T0() do {} while (0)
+#define TSQD_ACC(slot) do {} while (0)
+#define TSQD_CNT(slot, v) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(DecCfg::T) void dec_fast_kernel(const uint8_t* __restrict__ container,
                                                              const FrameInfo* __restrict__ frames,
                                                              uint8_t* __restrict__ outbuf,
@@ -101,6 +112,10 @@ __global__ __launch_bounds__(DecCfg::T) void dec_fast_kernel(const uint8_t* __re
     uint8_t* const out = outbuf + f.out_at;
     const uint32_t in_len = f.stream_len, size = f.out_len, ext = f.ext;
 
+#ifdef TSQ_STATS
+    unsigned long long st_[16] = {0};
+#endif
+    TSQD_T0();
     uint32_t sp = 3;      // stream position of the next group start
     uint32_t op = 0;      // output position reached
     if (tid == 0) misc[4] = 0;
@@ -128,6 +143,7 @@ __global__ __launch_bounds__(DecCfg::T) void dec_fast_kernel(const uint8_t* __re
         for (uint32_t k = tid; k < C::SPAD + 16; k += C::T) { uint32_t o = slim + k; if (o >= avail && o < C::S + C::SPAD + 16) sbuf[o] = 0; }
         __syncthreads();
 
+        TSQD_ACC(0); TSQD_CNT(12, 1);
         // ---------------- P1: speculative group parse at every offset
         for (uint32_t o = tid; o < C::S; o += C::T) {
             uint32_t nxt, olen = 0;
@@ -153,6 +169,7 @@ __global__ __launch_bounds__(DecCfg::T) void dec_fast_kernel(const uint8_t* __re
         }
         __syncthreads();
 
+        TSQD_ACC(1);
         // ---------------- P2: J = next^(2^D)
         {
             const uint16_t* src = nx1;
@@ -171,6 +188,7 @@ __global__ __launch_bounds__(DecCfg::T) void dec_fast_kernel(const uint8_t* __re
         }
         const uint16_t* const J = (C::D & 1u) ? ja : jb;          // D passes: ja, jb, ja, jb ...
 
+        TSQD_ACC(2);
         // ---------------- P3: one lane follows the chain of super nodes
         if (tid == 0) {
             uint32_t x = 0, k = 0;
@@ -181,6 +199,7 @@ __global__ __launch_bounds__(DecCfg::T) void dec_fast_kernel(const uint8_t* __re
         __syncthreads();
         const uint32_t nsn = misc[0];
 
+        TSQD_ACC(3);
         // ---------------- P4: expand super nodes into group starts; scan group lengths
         if (tid < nsn) {
             uint32_t x = sn[tid], cnt = 0;
@@ -229,6 +248,7 @@ __global__ __launch_bounds__(DecCfg::T) void dec_fast_kernel(const uint8_t* __re
         uint8_t* const obuf = o_raw + oskew;                       // obuf[q] <-> out[op + q], mutually 16-byte aligned
         __syncthreads();                                           // tables dead from here: syms may overwrite them
 
+        TSQD_ACC(4);
         // ---------------- P5: symbol records, one lane per group
         if (tid < ng) {
             const uint32_t x = gstart[tid];
@@ -273,6 +293,7 @@ __global__ __launch_bounds__(DecCfg::T) void dec_fast_kernel(const uint8_t* __re
         __syncthreads();
         if (misc[4] != 0) { if (tid == 0) atomicMax(status, (int32_t)misc[4]); return; }
 
+        TSQD_ACC(5);
         // ---------------- P6a: scatter literal and history bytes; record in-chunk sources
         for (uint32_t s = tid; s < ng * 8u; s += C::T) {
             const DecSym r = syms[s];
@@ -299,8 +320,10 @@ __global__ __launch_bounds__(DecCfg::T) void dec_fast_kernel(const uint8_t* __re
         }
         __syncthreads();
 
+        TSQD_ACC(6);
         // ---------------- P6b: pointer jumping until every byte of the image is final
         for (uint32_t round = 0; round < 20; ++round) {
+            TSQD_CNT(13, 1);
             uint32_t pend = 0;
             uint16_t np[C::OUTC / C::T];
             uint8_t nv[C::OUTC / C::T];
@@ -327,6 +350,7 @@ __global__ __launch_bounds__(DecCfg::T) void dec_fast_kernel(const uint8_t* __re
             if (!__syncthreads_or((int)pend)) break;
         }
 
+        TSQD_ACC(7);
         // ---------------- P7: image -> HBM (head bytes, aligned 16-byte words, tail bytes)
         {
             const uint32_t head = (16u - oskew) & 15u;
@@ -341,8 +365,12 @@ __global__ __launch_bounds__(DecCfg::T) void dec_fast_kernel(const uint8_t* __re
         __syncthreads();
         op = next_op;
         sp = next_sp;
+        TSQD_ACC(8); TSQD_CNT(14, ng);
         if (last_chunk) break;
     }
+#ifdef TSQ_STATS
+    if (blockIdx.x == 0 && tid == 0) for (int q = 0; q < 16; ++q) g_dec_stats[q] = st_[q];
+#endif
 }
 
 }  // namespace tsq

@@ -6,17 +6,26 @@
 #include "tsq_internal.h"
 #include "tsq_serial.cuh"
 #include "tsq_dec_fast.cuh"
+#include "tsq_enc_fast.cuh"
 
 namespace tsq {
 
-// Until the wave-parallel kernels land these forward to the serial kernels.
 inline int launch_encode_fast(tsqa_ctx* c, const uint8_t* in, size_t n, size_t readable, uint32_t ext, int32_t* status, hipStream_t s)
 {
     const uint32_t nb = (uint32_t)((n + kBlockSize - 1) / kBlockSize);
     int rc = c->reserve(nb, true);
     if (rc) return rc;
-    if (ext) hipLaunchKernelGGL(enc_serial_kernel<true>, dim3(nb), dim3(64), 0, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
-    else     hipLaunchKernelGGL(enc_serial_kernel<false>, dim3(nb), dim3(64), 0, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(enc_fast_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncLds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(enc_fast_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncLds) != hipSuccess) {
+            c->set_error("cannot reserve %u B of LDS", kEncLds);
+            return TSQA_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    if (ext) hipLaunchKernelGGL(enc_fast_kernel<true>, dim3(nb), dim3(64), kEncLds, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
+    else     hipLaunchKernelGGL(enc_fast_kernel<false>, dim3(nb), dim3(64), kEncLds, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
     return 0;
 }
 
