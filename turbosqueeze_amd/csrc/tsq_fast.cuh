@@ -7,6 +7,7 @@
 #include "tsq_serial.cuh"
 #include "tsq_dec_fast.cuh"
 #include "tsq_enc_fast.cuh"
+#include "tsq_enc_orbit.cuh"
 
 namespace tsq {
 
@@ -17,15 +18,22 @@ inline int launch_encode_fast(tsqa_ctx* c, const uint8_t* in, size_t n, size_t r
     if (rc) return rc;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(enc_fast_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncLds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(enc_fast_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncLds) != hipSuccess) {
-            c->set_error("cannot reserve %u B of LDS", kEncLds);
-            return TSQA_ERR_HIP;
-        }
+        const void* fns[4] = {reinterpret_cast<const void*>(enc_fast_kernel<true>), reinterpret_cast<const void*>(enc_fast_kernel<false>),
+                              reinterpret_cast<const void*>(enc_orbit_kernel<true>), reinterpret_cast<const void*>(enc_orbit_kernel<false>)};
+        for (const void* fn : fns)
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOrbLds) != hipSuccess) {
+                c->set_error("cannot reserve %u B of LDS", kOrbLds);
+                return TSQA_ERR_HIP;
+            }
         attr_set = true;
     }
-    if (ext) hipLaunchKernelGGL(enc_fast_kernel<true>, dim3(nb), dim3(64), kEncLds, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
-    else     hipLaunchKernelGGL(enc_fast_kernel<false>, dim3(nb), dim3(64), kEncLds, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
+    if (c->enc_variant == 2) {          // the windowed scalar walk (kept for A/B)
+        if (ext) hipLaunchKernelGGL(enc_fast_kernel<true>, dim3(nb), dim3(64), kEncLds, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
+        else     hipLaunchKernelGGL(enc_fast_kernel<false>, dim3(nb), dim3(64), kEncLds, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
+    } else {
+        if (ext) hipLaunchKernelGGL(enc_orbit_kernel<true>, dim3(nb), dim3(64), kOrbLds, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
+        else     hipLaunchKernelGGL(enc_orbit_kernel<false>, dim3(nb), dim3(64), kOrbLds, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
+    }
     return 0;
 }
 
