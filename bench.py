@@ -97,6 +97,50 @@ def cpu_baseline(sample_bytes: int, ext: int):
     }
 
 
+def init_distributed(backend: str):
+    """(world, rank, local_rank); one process per GPU, rendezvous on 127.0.0.1."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return world, rank, local_rank
+
+
+def timed_steps(step, steps: int, warmup: int, world: int, device_sync, reduce_device=None):
+    """W untimed steps, then exactly K steps bracketed by barrier + device sync on both sides;
+    returns the MAX over ranks of the elapsed seconds (the contract of the driver)."""
+    import torch
+    import torch.distributed as dist
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        device_sync()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=reduce_device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt
+
+
+def aggregate_value(world: int, bytes_per_rank: int, dt: float, steps: int):
+    """Whole-job GB/s over all ranks (weak scaling: every rank owns bytes_per_rank)."""
+    return world * bytes_per_rank / (dt / steps) / 1e9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,13 +158,7 @@ def main():
 
     import turbosqueeze_amd as tsq
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    world, rank, local_rank = init_distributed("nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -138,24 +176,14 @@ def main():
         codec.compress_async(src, args.ext, container)
         codec.decompress_async(container, nb, back)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
+    for _ in range(args.warmup):                      # W untimed, unprofiled steps
         step()
     torch.cuda.synchronize()
-    csize, status = codec.last_size_status()          # uncompressed total from the last decompress
-    assert status == 0, f"device status {status}"
-
-    codec.profile(True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    if args.warmup:
+        _, status = codec.last_size_status()
+        assert status == 0, f"device status {status}"
+    codec.profile(True)                               # HIP events around the kernels of the timed steps only
+    dt = timed_steps(step, args.steps, 0, world, torch.cuda.synchronize, dev)
     enc_ms, enc_n, dec_ms, dec_n = codec.profile_read()
     codec.profile(False)
 
@@ -168,12 +196,8 @@ def main():
     comp_bytes, status = codec.last_size_status()
     assert status == 0
 
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
-    value = world * n / (dt / args.steps) / 1e9
+    value = aggregate_value(world, n, dt, args.steps)
 
     if rank == 0:
         enc_avg = enc_ms / max(enc_n, 1) * 1e-3
@@ -201,7 +225,9 @@ def main():
             "decode_GBps": round(n / dec_avg / 1e9, 4) if dec_avg > 0 else 0.0,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n), args.ext)
+            # bounded sample, but never fewer blocks than 2 per host thread (block-parallel CPU code)
+            cores = os.cpu_count() or 1
+            line["cpu_baseline"] = cpu_baseline(min(n, max(args.cpu_sample, 2 * cores * tsq.BLOCK_SZ)), args.ext)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
