@@ -24,75 +24,61 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(sample_bytes: int, ext: int):
-    """Block-parallel CPU encode+decode of a bounded sample of the same workload, one thread per
-    core.  Uses the compiled reference (oracle/_ref) when present, else the oracle port."""
-    import ctypes as C
-    from concurrent.futures import ThreadPoolExecutor
+def pmc_traffic(kernel_substr: str):
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC summary of this same
+    command (tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes), corrected as
+    MI355X_MICROARCH.md prescribes for gfx950: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
+    bench.py cannot read PMCs itself; returns (bytes, source) or (None, None)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        f = next(v["per_dispatch"] for k, v in d["fetch"].items() if kernel_substr in k)
+        w = next(v["per_dispatch"] for k, v in d["write"].items() if kernel_substr in k)
+        return int((2 * f + w) * 1024), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
 
-    import numpy as np
+
+def cpu_baseline(sample_bytes: int, ext: int):
+    """Block-parallel CPU encode+decode of a bounded sample of the same workload on every host
+    thread (oracle/tsq_oracle.c: tsqo_cpubench, a pthread pool with block i -> thread i % T like
+    tsq_threads.cpp:71).  Runs the reference's own tsqEncode/tsqDecode (oracle/_ref) when that
+    library is present ("reference"), else the oracle port ("port")."""
+    import ctypes as C
 
     import turbosqueeze_amd as tsq
     from oracle import pyoracle
 
     cores = os.cpu_count() or 1
     host = tsq.synth.text(sample_bytes, seed=1, pad=256)
-    nb = (sample_bytes + (1 << 22) - 1) >> 22
-    kind = "reference" if pyoracle.Reference.available() else "port"
-    if kind == "reference":
-        L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libtsq_ref.so"))
-        u8p = C.c_void_p
-        L.tsqEncode.argtypes = [C.c_void_p, u8p, u8p, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32]
-        L.tsqDecode.argtypes = [u8p, u8p, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32]
-        slots = [np.zeros(pyoracle.OUTPUT_SZ + 4096, dtype=np.uint8) for _ in range(nb)]
-        sizes = [0] * nb
-        back = np.zeros(sample_bytes + 4096, dtype=np.uint8)
-
-        def enc(worker):
-            table = np.zeros(1 << 17, dtype=np.uint16)
-            ctx = pyoracle._RefCtx(table.ctypes.data)
-            sz = C.c_uint32(0)
-            for b in range(worker, nb, cores):                       # block i -> worker i % cores (tsq_threads.cpp:71)
-                at = b << 22
-                ln = min(1 << 22, sample_bytes - at)
-                table[:] = 0                                          # tsqInit
-                L.tsqEncode(C.byref(ctx), host.ctypes.data + at, slots[b].ctypes.data, C.byref(sz), ln, ext)
-                sizes[b] = sz.value
-
-        def dec(worker):
-            # the reference decoder over-copies past the block end (tsq_decode.cpp:60-90), so, like the
-            # reference's own workers (tsq_threads.cpp:590,648), decode into a private buffer and copy
-            sz = C.c_uint32(0)
-            scratch = np.zeros((1 << 22) + 4096, dtype=np.uint8)
-            for b in range(worker, nb, cores):
-                L.tsqDecode(slots[b].ctypes.data, scratch.ctypes.data, C.byref(sz), sizes[b], ext)
-                C.memmove(back.ctypes.data + (b << 22), scratch.ctypes.data, sz.value)
-
-        def run(fn):
-            t0 = time.perf_counter()
-            with ThreadPoolExecutor(cores) as ex:
-                list(ex.map(fn, range(cores)))
-            return time.perf_counter() - t0
-
-        run(enc); run(dec)                                            # warm (page faults)
-        te = min(run(enc) for _ in range(2))
-        td = min(run(dec) for _ in range(2))
-        ok = bool((back[:sample_bytes] == host[:sample_bytes]).all())
-    else:
-        orc = pyoracle.Oracle()
-        out = np.zeros(orc.L.tsqo_compress_bound(sample_bytes), dtype=np.uint8)
-        back = np.zeros(sample_bytes + 16, dtype=np.uint8)
-        sz = orc.compress_into(host, sample_bytes, out, ext, cores)
-        orc.decompress_into(out[:sz], back, cores)
-        te = td = 1e30
-        for _ in range(2):
-            t0 = time.perf_counter(); sz = orc.compress_into(host, sample_bytes, out, ext, cores); te = min(te, time.perf_counter() - t0)
-            t0 = time.perf_counter(); orc.decompress_into(out[:sz], back, cores); td = min(td, time.perf_counter() - t0)
-        ok = bool((back[:sample_bytes] == host[:sample_bytes]).all())
+    orc = pyoracle.Oracle()
+    fn = orc.L.tsqo_cpubench
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_int,
+                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    enc = dec = None
+    kind = "port"
+    if pyoracle.Reference.available():
+        ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libtsq_ref.so"))
+        enc = C.cast(ref.tsqEncode, C.c_void_p)
+        dec = C.cast(ref.tsqDecode, C.c_void_p)
+        kind = "reference"
+    best = None
+    for threads in sorted({cores, max(cores // 2, 1)}):           # SMT siblings do not always help: keep the better
+        te, td, cb = C.c_double(0), C.c_double(0), C.c_uint64(0)
+        bad = fn(enc, dec, host.ctypes.data, sample_bytes, ext, threads, 2, C.byref(te), C.byref(td), C.byref(cb))
+        r = {"threads": threads, "te": te.value, "td": td.value, "ok": bad == 0, "ratio": cb.value / sample_bytes}
+        if best is None or r["te"] + r["td"] < best["te"] + best["td"]:
+            best = r
+    te, td = best["te"], best["td"]
     return {
-        "value": round(sample_bytes / (te + td) / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": kind,
-        "sample": f"{sample_bytes} B of the same enwik9-shaped text, block-parallel (block i -> thread i % cores), "
-                  f"best of 2 warm passes, encode+decode; roundtrip_ok={ok}",
+        "value": round(sample_bytes / (te + td) / 1e9, 4), "unit": "GB/s", "cores": best["threads"], "kind": kind,
+        "sample": f"{sample_bytes} B of the same enwik9-shaped text, block-parallel pthreads (block i -> thread i % T), "
+                  f"best of 2 warm passes each for encode and decode; host has {cores} hardware threads; "
+                  f"roundtrip_ok={best['ok']} ratio={best['ratio']:.4f}",
         "encode_GBps": round(sample_bytes / te / 1e9, 4), "decode_GBps": round(sample_bytes / td / 1e9, 4),
     }
 
@@ -206,6 +192,9 @@ def main():
         enc_gbs = alg / enc_avg / 1e9 if enc_avg > 0 else 0.0
         dec_gbs = alg / dec_avg / 1e9 if dec_avg > 0 else 0.0
         dom = ("encode", enc_gbs, enc_avg) if enc_avg >= dec_avg else ("decode", dec_gbs, dec_avg)
+        traffic, traffic_src = (None, None)
+        if args.variant == 0 and args.ext == 0 and n == 1_000_000_000:
+            traffic, traffic_src = pmc_traffic("enc_" if dom[0] == "encode" else "dec_fast")
         line = {
             "metric": "encode+decode GB/s on enwik9-shaped input (round trip of uncompressed bytes)",
             "value": round(value, 4), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -216,7 +205,7 @@ def main():
                        "bytes_per_gpu": n, "blocks_per_gpu": nb, "ext": args.ext, "ratio": round(comp_bytes / n, 5),
                        "sharding": f"{world} independent shard(s), no data-path collective", "kernel_variant": args.variant},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(dom[1], 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(dom[1] / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(dom[1] / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(dom[2] * 1e3, 4)},
             "roofline_encode": {"achieved": round(enc_gbs, 3), "frac": round(enc_gbs / HBM_PEAK_GBS, 6), "avg_launch_ms": round(enc_avg * 1e3, 4), "launches": enc_n},
             "roofline_decode": {"achieved": round(dec_gbs, 3), "frac": round(dec_gbs / HBM_PEAK_GBS, 6), "avg_launch_ms": round(dec_avg * 1e3, 4), "launches": dec_n,

@@ -5,10 +5,12 @@
  * specification in SURVEY.md section 8a; every function cites the reference
  * lines whose behaviour it restates.  Plain C11, no dependencies.
  */
+#define _POSIX_C_SOURCE 200809L   /* pthread barriers, clock_gettime */
 #include "tsq_oracle.h"
 
 #include <pthread.h>
 #include <stdlib.h>
+#include <time.h>
 #include <string.h>
 
 /* ---- unaligned little-endian loads (tsq_common.h:115-118, tsq_encode.cpp:74,126) ---- */
@@ -410,4 +412,106 @@ uint64_t tsqo_fnv1a64(const uint8_t *p, size_t n)
     size_t i;
     for (i = 0; i < n; i++) { h ^= p[i]; h *= 0x100000001b3ull; }
     return h;
+}
+
+/* -------------------------------------------------------------------------
+ * CPU baseline driver for bench.py: block-parallel encode then decode of one
+ * buffer with a persistent pthread pool (block b -> thread b % T, the
+ * reference's assignment, tsq_threads.cpp:71), wall-clock per phase, best of
+ * `reps` after one untimed warm pass (page faults).  `enc`/`dec` are the
+ * reference's own tsqEncode/tsqDecode from oracle/_ref when supplied, else the
+ * port above.  Like the reference's workers, decode goes to a private buffer
+ * and is then copied (tsq_threads.cpp:590,648), because the reference decoder
+ * over-copies past the block end.
+ * ---------------------------------------------------------------------- */
+typedef void (*tsqo_enc_fn)(void *ctx, uint8_t *in, uint8_t *out, uint32_t *outsz, uint32_t insz, uint32_t ext);
+typedef void (*tsqo_dec_fn)(uint8_t *in, uint8_t *out, uint32_t *outsz, uint32_t insz, uint32_t ext);
+
+typedef struct {
+    tsqo_enc_fn enc; tsqo_dec_fn dec;
+    const uint8_t *in; size_t n; uint32_t ext; size_t nb;
+    uint8_t *slots; size_t stride; uint32_t *sizes; uint8_t *back;
+    int nthreads; int phase;            /* 0 encode, 1 decode, 2 quit */
+    pthread_barrier_t go, done;
+} bench_shared;
+typedef struct { bench_shared *sh; int tid; } bench_arg;
+
+static void *bench_worker(void *p)
+{
+    bench_arg *a = (bench_arg *)p;
+    bench_shared *sh = a->sh;
+    uint16_t *table = (uint16_t *)aligned_alloc(128, TSQO_HASH_ENTRIES * sizeof(uint16_t));
+    uint8_t *scratch = (uint8_t *)malloc(TSQO_BLOCK_SZ + 4096);
+    struct { uint16_t *refhash; } ctx = { table };
+    memset(scratch, 0, TSQO_BLOCK_SZ + 4096);
+    for (;;) {
+        size_t b;
+        pthread_barrier_wait(&sh->go);
+        if (sh->phase == 2) break;
+        for (b = (size_t)a->tid; b < sh->nb; b += (size_t)sh->nthreads) {
+            size_t at = b * TSQO_BLOCK_SZ;
+            uint32_t len = (uint32_t)(sh->n - at < TSQO_BLOCK_SZ ? sh->n - at : TSQO_BLOCK_SZ), sz = 0;
+            uint8_t *slot = sh->slots + b * sh->stride;
+            if (sh->phase == 0) {
+                if (sh->enc) { memset(table, 0, TSQO_HASH_ENTRIES * sizeof(uint16_t)); sh->enc(&ctx, (uint8_t *)sh->in + at, slot, &sz, len, sh->ext); }
+                else sz = tsqo_encode_block(sh->in + at, len, slot, sh->ext, table);
+                sh->sizes[b] = sz;
+            } else {
+                if (sh->dec) { sh->dec(slot, scratch, &sz, sh->sizes[b], sh->ext); memcpy(sh->back + at, scratch, sz); }
+                else { int st; tsqo_decode_block(slot, sh->sizes[b], sh->back + at, sh->ext, &st); }
+            }
+        }
+        pthread_barrier_wait(&sh->done);
+    }
+    free(table); free(scratch);
+    return NULL;
+}
+
+#include <time.h>
+static double wall_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
+/* `in` needs TSQO_HALO readable bytes after in[n-1].  Returns 0 when the round trip is exact. */
+int tsqo_cpubench(void *enc, void *dec, const uint8_t *in, size_t n, uint32_t ext, int threads, int reps,
+                  double *enc_seconds, double *dec_seconds, uint64_t *compressed_bytes)
+{
+    bench_shared sh;
+    pthread_t *th; bench_arg *args;
+    int t, r, bad;
+    double best_e = 1e30, best_d = 1e30;
+    size_t b;
+    if (threads < 1) threads = 1;
+    memset(&sh, 0, sizeof sh);
+    sh.enc = (tsqo_enc_fn)enc; sh.dec = (tsqo_dec_fn)dec; sh.in = in; sh.n = n; sh.ext = ext;
+    sh.nb = (n + TSQO_BLOCK_SZ - 1) / TSQO_BLOCK_SZ;
+    sh.stride = ((size_t)tsqo_bound(TSQO_BLOCK_SZ) + 4096 + 4095) & ~(size_t)4095;
+    sh.slots = (uint8_t *)malloc(sh.nb * sh.stride);
+    sh.sizes = (uint32_t *)calloc(sh.nb, sizeof(uint32_t));
+    sh.back = (uint8_t *)malloc(n + 4096);
+    sh.nthreads = threads;
+    memset(sh.slots, 0, sh.nb * sh.stride);       /* canonical zero-filled output; also pre-faults */
+    memset(sh.back, 0, n + 4096);
+    pthread_barrier_init(&sh.go, NULL, (unsigned)threads + 1);
+    pthread_barrier_init(&sh.done, NULL, (unsigned)threads + 1);
+    th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+    args = (bench_arg *)malloc(sizeof(bench_arg) * (size_t)threads);
+    for (t = 0; t < threads; t++) { args[t].sh = &sh; args[t].tid = t; pthread_create(&th[t], NULL, bench_worker, &args[t]); }
+    for (r = 0; r <= reps; r++) {                 /* r == 0 is the warm pass */
+        double t0, t1, t2;
+        sh.phase = 0; t0 = wall_now();
+        pthread_barrier_wait(&sh.go); pthread_barrier_wait(&sh.done);
+        t1 = wall_now(); sh.phase = 1;
+        pthread_barrier_wait(&sh.go); pthread_barrier_wait(&sh.done);
+        t2 = wall_now();
+        if (r > 0) { if (t1 - t0 < best_e) best_e = t1 - t0; if (t2 - t1 < best_d) best_d = t2 - t1; }
+    }
+    sh.phase = 2;
+    pthread_barrier_wait(&sh.go);
+    for (t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    bad = memcmp(sh.back, in, n) != 0;
+    if (compressed_bytes) { uint64_t c = 16; for (b = 0; b < sh.nb; b++) c += 3 + sh.sizes[b]; *compressed_bytes = c; }
+    if (enc_seconds) *enc_seconds = best_e;
+    if (dec_seconds) *dec_seconds = best_d;
+    pthread_barrier_destroy(&sh.go); pthread_barrier_destroy(&sh.done);
+    free(th); free(args); free(sh.slots); free(sh.sizes); free(sh.back);
+    return bad;
 }

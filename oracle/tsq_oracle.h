@@ -71,6 +71,12 @@ size_t tsqo_compress(const uint8_t *in, size_t n, uint8_t *out, uint32_t ext, in
 size_t tsqo_decompressed_size(const uint8_t *in, size_t n);
 size_t tsqo_decompress(const uint8_t *in, size_t n, uint8_t *out, size_t out_cap, int threads);
 
+/* CPU baseline for bench.py: block-parallel encode+decode on `threads` pthreads, best of `reps`
+ * warm passes.  enc/dec: addresses of the reference's tsqEncode/tsqDecode (oracle/_ref) or NULL
+ * for the port.  Returns 0 when the round trip reproduced the input. */
+int tsqo_cpubench(void *enc, void *dec, const uint8_t *in, size_t n, uint32_t ext, int threads, int reps,
+                  double *enc_seconds, double *dec_seconds, uint64_t *compressed_bytes);
+
 /* FNV-1a 64 (basis cbf29ce484222325, prime 100000001b3). */
 uint64_t tsqo_fnv1a64(const uint8_t *p, size_t n);
 
