@@ -8,6 +8,7 @@
 #include "tsq_dec_fast.cuh"
 #include "tsq_enc_fast.cuh"
 #include "tsq_enc_orbit.cuh"
+#include "tsq_enc_pipe.cuh"
 
 namespace tsq {
 
@@ -18,11 +19,12 @@ inline int launch_encode_fast(tsqa_ctx* c, const uint8_t* in, size_t n, size_t r
     if (rc) return rc;
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[4] = {reinterpret_cast<const void*>(enc_fast_kernel<true>), reinterpret_cast<const void*>(enc_fast_kernel<false>),
-                              reinterpret_cast<const void*>(enc_orbit_kernel<true>), reinterpret_cast<const void*>(enc_orbit_kernel<false>)};
+        const void* fns[6] = {reinterpret_cast<const void*>(enc_fast_kernel<true>), reinterpret_cast<const void*>(enc_fast_kernel<false>),
+                              reinterpret_cast<const void*>(enc_orbit_kernel<true>), reinterpret_cast<const void*>(enc_orbit_kernel<false>),
+                              reinterpret_cast<const void*>(enc_pipe_kernel<true>), reinterpret_cast<const void*>(enc_pipe_kernel<false>)};
         for (const void* fn : fns)
-            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOrbLds) != hipSuccess) {
-                c->set_error("cannot reserve %u B of LDS", kOrbLds);
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PipeCfg::total) != hipSuccess) {
+                c->set_error("cannot reserve %u B of LDS", PipeCfg::total);
                 return TSQA_ERR_HIP;
             }
         attr_set = true;
@@ -30,9 +32,12 @@ inline int launch_encode_fast(tsqa_ctx* c, const uint8_t* in, size_t n, size_t r
     if (c->enc_variant == 2) {          // the windowed scalar walk (kept for A/B)
         if (ext) hipLaunchKernelGGL(enc_fast_kernel<true>, dim3(nb), dim3(64), kEncLds, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
         else     hipLaunchKernelGGL(enc_fast_kernel<false>, dim3(nb), dim3(64), kEncLds, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
-    } else {
+    } else if (c->enc_variant == 3) {   // single-wave orbit encoder (kept for A/B)
         if (ext) hipLaunchKernelGGL(enc_orbit_kernel<true>, dim3(nb), dim3(64), kOrbLds, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
         else     hipLaunchKernelGGL(enc_orbit_kernel<false>, dim3(nb), dim3(64), kOrbLds, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
+    } else {                            // two-wave pipeline: parser + builder
+        if (ext) hipLaunchKernelGGL(enc_pipe_kernel<true>, dim3(nb), dim3(128), PipeCfg::total, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
+        else     hipLaunchKernelGGL(enc_pipe_kernel<false>, dim3(nb), dim3(128), PipeCfg::total, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
     }
     return 0;
 }
