@@ -116,7 +116,7 @@ int tsqa_profile_read(tsqa_ctx *ctx, double *encode_ms, uint32_t *encode_launche
                       double *decode_ms, uint32_t *decode_launches);
 
 /* Kernel variant selection for A/B measurements: 0 = default (fastest validated), 2 = windowed
- * scalar-walk encoder, 3 = single-wave orbit encoder (encode only),
+ * scalar-walk encoder, 3 = single-wave orbit encoder, 4 = two-wave parser/builder encoder (encode only),
  * 1 = serial reference kernels (one lane walks the block; correctness baseline). */
 void tsqa_set_kernel_variant(tsqa_ctx *ctx, int encode_variant, int decode_variant);
 

@@ -32,12 +32,9 @@ enc = (C.c_ulonglong * 16)()
 dec = (C.c_ulonglong * 16)()
 L.tsqa_debug_stats(enc, dec)
 e = list(enc); d = list(dec)
-tot = e[13] + e[0] + e[1] + e[2] + e[3] + e[8] + e[14]
-print(f"ENC parser block0 (cycles, s_memtime-instrumented): input-load={e[13]} gather+classify={e[0]} orbit={e[1]} account={e[3]} send={e[14]} serial={e[8]} commit={e[2]} total={tot}")
-print(f"  windows={e[4]} segments={e[5]} serial_visits={e[7]} symbols={e[9]}")
-if e[4]:
-    w = e[4]
-    print(f"  per window: input-load={e[13]/w:.0f} gather+classify={e[0]/w:.0f} orbit={e[1]/w:.0f} account={e[3]/w:.0f} send={e[14]/w:.0f} serial={e[8]/w:.0f} commit={e[2]/w:.0f}; per serial visit={e[8]/max(e[7],1):.0f}")
+print(f"ENC tile pipeline block0 (cycles): FRONT wait-for-parser={e[0]} commit={e[1]} classify={e[2]} tiles={e[3]} | PARSER wait-for-front={e[4]} work={e[5]} tiles={e[6]} symbols={e[9]}")
+if e[3] and e[6]:
+    print(f"  per tile: front wait={e[0]/e[3]:.0f} commit={e[1]/e[3]:.0f} classify={e[2]/e[3]:.0f} | parser wait={e[4]/e[6]:.0f} work={e[5]/e[6]:.0f}")
 names = ["P0 stage", "P1 spec", "P2 dbl", "P3 chain", "P4 expand+scan", "P5 syms", "P6a scatter", "P6b jump", "P7 flush"]
 dt = sum(d[:9])
 print(f"DEC block0: total ticks={dt} chunks={d[12]} jump rounds={d[13]} groups={d[14]}")

@@ -322,9 +322,11 @@ __device__ __forceinline__ void pipe_parser(const uint8_t* src, uint64_t avail, 
     }
 }
 
+template <class Cfg>
 __device__ __forceinline__ void pipe_builder(const uint8_t* src, uint64_t avail, uint8_t* out, lds_u8_t* lds, uint32_t lane,
                                              uint32_t b, uint32_t* sizes, int32_t* status)
 {
+    using PipeCfg = Cfg;
     volatile lds_u32_t* queue = (volatile lds_u32_t*)(lds + PipeCfg::off_queue);
     volatile lds_u32_t* ring = (volatile lds_u32_t*)(lds + PipeCfg::off_ring);
     lds_u32_t* ctl = (lds_u32_t*)(lds + PipeCfg::off_ctl);
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(128) void enc_pipe_kernel(const uint8_t* __restrict
     __syncthreads();
     lds_u8_t* lds3 = (lds_u8_t*)pipe_lds;
     if (role == 0) pipe_parser<EXT>(src, avail, n, table, lds3, lane, b);
-    else pipe_builder(src, avail, out, lds3, lane, b, sizes, status);
+    else pipe_builder<PipeCfg>(src, avail, out, lds3, lane, b, sizes, status);
 }
 
 }  // namespace tsq

@@ -9,6 +9,7 @@
 #include "tsq_enc_fast.cuh"
 #include "tsq_enc_orbit.cuh"
 #include "tsq_enc_pipe.cuh"
+#include "tsq_enc_tile.cuh"
 
 namespace tsq {
 
@@ -19,12 +20,13 @@ inline int launch_encode_fast(tsqa_ctx* c, const uint8_t* in, size_t n, size_t r
     if (rc) return rc;
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[6] = {reinterpret_cast<const void*>(enc_fast_kernel<true>), reinterpret_cast<const void*>(enc_fast_kernel<false>),
+        const void* fns[8] = {reinterpret_cast<const void*>(enc_tile_kernel<true>), reinterpret_cast<const void*>(enc_tile_kernel<false>),
+                              reinterpret_cast<const void*>(enc_fast_kernel<true>), reinterpret_cast<const void*>(enc_fast_kernel<false>),
                               reinterpret_cast<const void*>(enc_orbit_kernel<true>), reinterpret_cast<const void*>(enc_orbit_kernel<false>),
                               reinterpret_cast<const void*>(enc_pipe_kernel<true>), reinterpret_cast<const void*>(enc_pipe_kernel<false>)};
         for (const void* fn : fns)
-            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PipeCfg::total) != hipSuccess) {
-                c->set_error("cannot reserve %u B of LDS", PipeCfg::total);
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TileCfg::total) != hipSuccess) {
+                c->set_error("cannot reserve %u B of LDS", TileCfg::total);
                 return TSQA_ERR_HIP;
             }
         attr_set = true;
@@ -35,9 +37,12 @@ inline int launch_encode_fast(tsqa_ctx* c, const uint8_t* in, size_t n, size_t r
     } else if (c->enc_variant == 3) {   // single-wave orbit encoder (kept for A/B)
         if (ext) hipLaunchKernelGGL(enc_orbit_kernel<true>, dim3(nb), dim3(64), kOrbLds, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
         else     hipLaunchKernelGGL(enc_orbit_kernel<false>, dim3(nb), dim3(64), kOrbLds, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
-    } else {                            // two-wave pipeline: parser + builder
+    } else if (c->enc_variant == 4) {   // two-wave pipeline: parser + builder (kept for A/B)
         if (ext) hipLaunchKernelGGL(enc_pipe_kernel<true>, dim3(nb), dim3(128), PipeCfg::total, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
         else     hipLaunchKernelGGL(enc_pipe_kernel<false>, dim3(nb), dim3(128), PipeCfg::total, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
+    } else {                            // three-wave tile pipeline: front + parser + builder
+        if (ext) hipLaunchKernelGGL(enc_tile_kernel<true>, dim3(nb), dim3(192), TileCfg::total, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
+        else     hipLaunchKernelGGL(enc_tile_kernel<false>, dim3(nb), dim3(192), TileCfg::total, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
     }
     return 0;
 }
