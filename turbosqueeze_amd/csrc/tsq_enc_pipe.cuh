@@ -86,7 +86,7 @@ __device__ __forceinline__ void pipe_parser(const uint8_t* src, uint64_t avail, 
     const uint32_t tail_from = n >= 5u ? n - 5u : 0u;
     (void)b;
 
-    uint32_t head = 0;             // items published so far
+    uint32_t head = 0, tail_seen = 0;   // items published so far; last value read of the builder's progress
     uint32_t v = 1, nsym = 0, origin = 0, lit_from = 0;
     bool after_match = false;
     uint32_t run0 = 0, origin_r0 = 0, odd_r0 = 0;
@@ -94,7 +94,10 @@ __device__ __forceinline__ void pipe_parser(const uint8_t* src, uint64_t avail, 
 
     // reserve the next queue slot (back-pressure on the builder), fill it, publish it
     auto slot_begin = [&]() -> volatile lds_u32_t* {
-        while (head - __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= PipeCfg::Q) __builtin_amdgcn_s_sleep(2);
+        while (head - tail_seen >= PipeCfg::Q) {
+            tail_seen = uniform(__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (head - tail_seen >= PipeCfg::Q) __builtin_amdgcn_s_sleep(2);
+        }
         return queue + (head % PipeCfg::Q) * PipeCfg::ITEM_WORDS;
     };
     auto slot_publish = [&]() {

@@ -39,7 +39,7 @@ struct TileCfg {
 };
 // ctl words: 0 queue head, 1 queue tail, 2 tiles classified, 3 tiles parsed, 4 stop,
 //            8 + 2*(t&3): visited mask of tile t (lo, hi)
-// record header: 0,1 hard  2,3 flagged  4,5 certain      arrays: 0 spanword 1 cand|nib 2 h 3 w 4,5 twin_in 6,7 twin_prev
+// record header: 0,1 hard  2,3 flagged  4,5 certain      arrays: 0 spanword 1 cand|nib 2 four-hop word 3 w 4,5 twin_in 6,7 twin_prev
 // spanword: natural span (bits 0..7) | stop (bit 8) | common prefix (bits 16..23)
 
 template <bool EXT>
@@ -141,6 +141,24 @@ __device__ __forceinline__ void tile_front(const uint8_t* src, uint64_t avail, u
         const bool hard_l = (eq4 && !far_enough) || tail;
         const bool twin_l = (twin_in | twin_prev) != 0ull;
         const uint64_t hard = __ballot(hard_l), flagged = __ballot(twin_l), certain_m = __ballot(certain);
+        // the next four orbit hops of every lane, each as (lane or position-past-the-tile: 7 bits | halted: bit 7);
+        // a hop halts when it lands on a hard lane or past the tile, and later hops repeat it.  Twin lanes do
+        // not halt: the parser runs the orbit optimistically and checks the visited twins afterwards.
+        uint32_t hops;
+        {
+            const uint32_t self = lane | (hard_l ? 0x80u : 0u);                    // arriving at this lane: halts?
+            auto land = [&](uint32_t c) -> uint32_t {                               // c = lane + span, < 128
+                const uint32_t there = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((c & 63u) << 2), (int)self);
+                return c >= 64u ? (c | 0x80u) : there;
+            };
+            const uint32_t h1 = land(lane + span_nat);                              // hop 1 of this lane
+            auto next_of = [&](uint32_t hv) -> uint32_t {                           // hop 1 of the lane a hop value points at
+                const uint32_t there = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((hv & 63u) << 2), (int)h1);
+                return (hv & 0x80u) ? hv : there;
+            };
+            const uint32_t h2 = next_of(h1), h3 = next_of(h2), h4 = next_of(h3);
+            hops = h1 | (h2 << 8) | (h3 << 16) | (h4 << 24);
+        }
 
         volatile lds_u32_t* rec = recs + (t & 1u) * TileCfg::REC_WORDS;
         if (lane == 0) {
@@ -150,7 +168,7 @@ __device__ __forceinline__ void tile_front(const uint8_t* src, uint64_t avail, u
         }
         rec[16 + 0 * 64 + lane] = span_nat | ((hard_l || twin_l) ? 256u : 0u) | (k0 << 16);
         rec[16 + 1 * 64 + lane] = cand0 | (nib << 24);
-        rec[16 + 2 * 64 + lane] = h;
+        rec[16 + 2 * 64 + lane] = hops;
         rec[16 + 3 * 64 + lane] = w;
         rec[16 + 4 * 64 + lane] = (uint32_t)twin_in;
         rec[16 + 5 * 64 + lane] = (uint32_t)(twin_in >> 32);
@@ -158,6 +176,8 @@ __device__ __forceinline__ void tile_front(const uint8_t* src, uint64_t avail, u
         rec[16 + 7 * 64 + lane] = (uint32_t)(twin_prev >> 32);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(&ctl[2], t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (prefetching the next tile's input words here was measured and does not pay: loads and stores retire in
+        //  order, so the prefetch either delays this tile's gathers or makes the next step wait for the commit stores)
         h_m2 = h_m1; h_m1 = h;
         twins_m2 = twins_m1; twins_m1 = twins_here;
         TSQ_ACC(2);
@@ -167,6 +187,42 @@ __device__ __forceinline__ void tile_front(const uint8_t* src, uint64_t avail, u
     }
 }
 
+// Orbit over precomputed four-hop words: one v_readlane per four visits.  On entry lane L (< 64) is
+// a normal lane not yet in V.  Returns with L = the lane (or position past the tile, >= 64) the
+// orbit halted on, which is NOT added to V.
+__device__ __forceinline__ void orbit_run4(uint32_t hops, uint32_t& L, uint64_t& V)
+{
+    uint32_t w;
+    uint64_t bit;
+    asm volatile(
+        "1:\n\t"
+        "v_readlane_b32 %[w], %[hops], %[L]\n\t"
+        "s_lshl_b64 %[bit], 1, %[L]\n\t"
+        "s_or_b64 %[V], %[V], %[bit]\n\t"
+        "s_and_b32 %[L], %[w], 0x7f\n\t"
+        "s_bitcmp1_b32 %[w], 7\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_lshl_b64 %[bit], 1, %[L]\n\t"
+        "s_or_b64 %[V], %[V], %[bit]\n\t"
+        "s_bfe_u32 %[L], %[w], 0x70008\n\t"
+        "s_bitcmp1_b32 %[w], 15\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_lshl_b64 %[bit], 1, %[L]\n\t"
+        "s_or_b64 %[V], %[V], %[bit]\n\t"
+        "s_bfe_u32 %[L], %[w], 0x70010\n\t"
+        "s_bitcmp1_b32 %[w], 23\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_lshl_b64 %[bit], 1, %[L]\n\t"
+        "s_or_b64 %[V], %[V], %[bit]\n\t"
+        "s_bfe_u32 %[L], %[w], 0x70018\n\t"
+        "s_bitcmp1_b32 %[w], 31\n\t"
+        "s_cbranch_scc0 1b\n"
+        "2:\n\t"
+        : [L] "+s"(L), [V] "+s"(V), [w] "=&s"(w), [bit] "=&s"(bit)
+        : [hops] "v"(hops)
+        : "scc");
+}
+
 template <bool EXT>
 __device__ __forceinline__ void tile_parser(const uint8_t* src, uint64_t avail, uint32_t n, lds_u8_t* lds, uint32_t lane)
 {
@@ -174,7 +230,7 @@ __device__ __forceinline__ void tile_parser(const uint8_t* src, uint64_t avail, 
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + TileCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + TileCfg::off_ctl);
 
-    uint32_t head = 0;
+    uint32_t head = 0, tail_seen = 0;  // tail_seen: last value read of the builder's progress (re-read only when the queue looks full)
     uint32_t v = 1, nsym = 0, origin = 0, lit_from = 0;
     bool after_match = false;
     uint32_t run0 = 0, origin_r0 = 0, odd_r0 = 0;
@@ -182,7 +238,10 @@ __device__ __forceinline__ void tile_parser(const uint8_t* src, uint64_t avail, 
     uint64_t vall_prev = 0;            // visited lanes of the previous tile
 
     auto slot_begin = [&]() -> volatile lds_u32_t* {
-        while (head - __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= TileCfg::Q) __builtin_amdgcn_s_sleep(2);
+        while (head - tail_seen >= TileCfg::Q) {
+            tail_seen = uniform(__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (head - tail_seen >= TileCfg::Q) __builtin_amdgcn_s_sleep(2);
+        }
         return queue + (head % TileCfg::Q) * TileCfg::ITEM_WORDS;
     };
     auto slot_publish = [&]() {
@@ -214,12 +273,12 @@ __device__ __forceinline__ void tile_parser(const uint8_t* src, uint64_t avail, 
             const uint64_t hard = (uint64_t)uniform(rec[0]) | ((uint64_t)uniform(rec[1]) << 32);
             const uint64_t certain_m = (uint64_t)uniform(rec[4]) | ((uint64_t)uniform(rec[5]) << 32);
             const uint32_t spanword = rec[16 + 0 * 64 + lane];
+            const uint32_t hops = rec[16 + 2 * 64 + lane];
             const uint32_t lane_word = rec[16 + 1 * 64 + lane];
             const uint32_t w = rec[16 + 3 * 64 + lane];
             const uint32_t tin_lo = rec[16 + 4 * 64 + lane], tin_hi = rec[16 + 5 * 64 + lane];
             const uint32_t tpv_lo = rec[16 + 6 * 64 + lane], tpv_hi = rec[16 + 7 * 64 + lane];
             const uint32_t span_nat = spanword & 0xFFu;
-            const uint32_t span = (spanword & 256u) ? kStopSpan : span_nat;
             const uint32_t k0 = (spanword >> 16) & 0xFFu;
             const uint32_t cand0 = lane_word & 0xFFFFFFu;
 
@@ -339,24 +398,33 @@ __device__ __forceinline__ void tile_parser(const uint8_t* src, uint64_t avail, 
             };
 
             uint32_t L = v - base;
+            TSQ_ACC(7);
             while (!done) {
                 uint64_t V = 0;
                 const uint32_t seg_nsym = nsym, seg_origin = origin, seg_lit_from = lit_from;
                 bool tile_end = false;
-                for (;;) {
-                    if (!orbit_run(span, L, V)) { tile_end = true; break; }
-                    if ((hard >> L) & 1ull) break;
-                    uint64_t in_tile, in_prev;
-                    visited_twins(L, vall | V, in_tile, in_prev);
-                    if (in_tile | in_prev) break;               // a twin was visited: the gathered candidate is not current
-                    V |= 1ull << L;
-                    L += rdlane(span_nat, L);
+                if (L < 64u && !((hard >> L) & 1ull)) orbit_run4(hops, L, V);   // halts on a hard lane or past the tile
+                {
+                    // the orbit treated twin lanes as ordinary lanes.  That is wrong for a visited lane that has a
+                    // VISITED twin before it (earlier in this tile, or in the previous tile): its gathered candidate
+                    // is not current.  The first such lane ends the segment; everything before it is exact.
+                    const uint64_t seen = vall | V;
+                    const bool stale = ((V >> lane) & 1ull) &&
+                                       (((tin_lo & (uint32_t)seen) | (tin_hi & (uint32_t)(seen >> 32)) |
+                                         (tpv_lo & (uint32_t)vall_prev) | (tpv_hi & (uint32_t)(vall_prev >> 32))) != 0u);
+                    const uint64_t bad = __ballot(stale);
+                    if (bad) { L = lsb64(bad); V &= below(L); }
                 }
+                tile_end = L >= 64u;
+                TSQ_ACC(8);
                 account_segment(V);
+                TSQ_ACC(10);
                 send_segment(V, seg_nsym, seg_origin, seg_lit_from);
+                TSQ_ACC(11);
                 vall |= V;
                 if (tile_end) { v = base + L; break; }
                 visit_serial(L);
+                TSQ_ACC(12);
                 L = v - base;
             }
         }
@@ -372,7 +440,7 @@ __device__ __forceinline__ void tile_parser(const uint8_t* src, uint64_t avail, 
     }
 #ifdef TSQ_STATS
     TSQ_ACC(5);
-    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[4] = st_[4]; g_enc_stats[5] = st_[5]; g_enc_stats[6] = st_[6]; g_enc_stats[9] = nsym; }
+    if (blockIdx.x == 0 && lane == 0) { for (int q = 4; q < 13; ++q) g_enc_stats[q] = st_[q]; g_enc_stats[9] = nsym; }
 #endif
     if (lane == 0) __hip_atomic_store(&ctl[4], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     {
