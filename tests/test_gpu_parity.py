@@ -98,6 +98,27 @@ def test_fuzz_containers_vs_oracle(codec, oracle):
             assert to_bytes(codec.decompress(blob)) == data.tobytes(), (case, n, ext)
 
 
+def test_literal_runs_across_tiles_and_equal_byte_runs(codec, oracle, tsq):
+    """Long literal runs whose 16-byte chunking is not aligned with the encoder's 64-position tiles
+    (a full tile of literals with carried bytes), and runs of equal / short-period bytes (every
+    lane shares its hash with its neighbours): the encoder's fast paths for both must stay exact."""
+    rng = np.random.default_rng(77)
+    cases = []
+    for shift in range(0, 70, 7):
+        head = (b"0123456789abcdef" * 8)[: 64 + shift]
+        cases.append(np.frombuffer(head + rng.integers(0, 256, size=3000, dtype=np.uint8).tobytes() + head, dtype=np.uint8))
+    for period in (1, 2, 3, 4, 5, 7, 16, 63, 64, 65):
+        unit = rng.integers(0, 256, size=period, dtype=np.uint8)
+        body = np.resize(unit, 5000)
+        cases.append(np.concatenate([rng.integers(0, 256, size=37, dtype=np.uint8), body, rng.integers(0, 256, size=200, dtype=np.uint8), body[:777]]))
+    cases.append(np.concatenate([np.zeros(70000, dtype=np.uint8), np.full(70000, 255, dtype=np.uint8), np.zeros(999, dtype=np.uint8)]))
+    for k, data in enumerate(cases):
+        for ext in (0, 1):
+            blob = codec.compress(to_dev(data), ext)
+            assert to_bytes(blob) == oracle.compress(data, ext), (k, ext)
+            assert to_bytes(codec.decompress(blob)) == data.tobytes(), (k, ext)
+
+
 def test_multiblock_halo_and_short_tail(codec, oracle, tsq):
     """Blocks are contiguous: block k's look-ahead reads block k+1 (SURVEY.md 8c canonical conditions)."""
     n = 3 * (1 << 22) + 77777

@@ -40,6 +40,12 @@ __device__ uint32_t g_dbg_syms[8192];
 #endif
 __device__ __forceinline__ uint32_t msb64(uint64_t m) { return 63u - (uint32_t)__builtin_clzll(m); }
 __device__ __forceinline__ uint32_t lsb64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
+// number of consecutive set bits of `mask` starting at bit `from` (a run that reaches bit 63 included)
+__device__ __forceinline__ uint32_t ones_from(uint64_t mask, uint32_t from)
+{
+    const uint64_t inv = ~(mask >> from);            // zero only when from == 0 and every bit is set
+    return inv ? (uint32_t)__builtin_ctzll(inv) : 64u - from;
+}
 
 template <bool EXT>
 __global__ __launch_bounds__(64) void enc_orbit_kernel(const uint8_t* __restrict__ in, uint64_t n_total, uint64_t readable,
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(64) void enc_orbit_kernel(const uint8_t* __restrict
             const uint32_t nsym_entry = nsym, origin_entry = origin;
             const uint64_t M = V & certain_m, N = V & ~certain_m;
             const uint32_t Ls = lsb64(V), Le = msb64(V);
-            const uint32_t len_first = ((N >> Ls) & 1ull) ? lsb64(~(N >> Ls)) : 0u;      // N lanes contiguous from Ls
+            const uint32_t len_first = ((N >> Ls) & 1ull) ? ones_from(N, Ls) : 0u;      // N lanes contiguous from Ls
             const uint64_t startN = N & ~(N << 1);
             const bool isM = (M >> lane) & 1ull, isN = (N >> lane) & 1ull;
             const bool in_first = lane >= Ls && lane < Ls + len_first;

@@ -261,7 +261,7 @@ __device__ __forceinline__ void pipe_parser(const uint8_t* src, uint64_t avail, 
             const bool first_isN = (N >> Ls) & 1ull;
             uint64_t t = N & (N >> 1); t &= t >> 2; t &= t >> 4; t &= t >> 8;      // a run of 16 literal lanes
             const uint32_t carried = first_isN ? base + Ls - lit_from : 0u;
-            const uint32_t first_len = first_isN ? lsb64(~(N >> Ls)) : 0u;
+            const uint32_t first_len = first_isN ? ones_from(N, Ls) : 0u;
             if (t != 0ull || carried + first_len >= 16u) { replay_segment(V); return; }
             if (M == 0ull) {
                 if (after_match) { run0 = base + Ls; origin_r0 = origin; odd_r0 = nsym & 1u; after_match = false; }
@@ -375,7 +375,7 @@ __device__ __forceinline__ void pipe_builder(const uint8_t* src, uint64_t avail,
             }
             // the pair origin seen by an odd first symbol: the parser's origin, unless the literal above was symbol idx0-1
             const uint32_t first_prev_start = (idx0 != nsym_entry) ? uniform(it[6]) : origin_entry;
-            const uint32_t len_first = ((N >> Ls) & 1ull) ? lsb64(~(N >> Ls)) : 0u;
+            const uint32_t len_first = ((N >> Ls) & 1ull) ? ones_from(N, Ls) : 0u;
             const uint64_t startN = N & ~(N << 1);
             const bool isM = (M >> lane) & 1ull, isN = (N >> lane) & 1ull;
             const bool in_first = lane >= Ls && lane < Ls + len_first;

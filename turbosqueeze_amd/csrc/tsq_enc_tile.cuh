@@ -39,7 +39,7 @@ struct TileCfg {
 };
 // ctl words: 0 queue head, 1 queue tail, 2 tiles classified, 3 tiles parsed, 4 stop,
 //            8 + 2*(t&3): visited mask of tile t (lo, hi)
-// record header: 0,1 hard  2,3 flagged  4,5 certain      arrays: 0 spanword 1 cand|nib 2 four-hop word 3 w 4,5 twin_in 6,7 twin_prev
+// record header: 0,1 hard  2,3 flagged  4,5 certain  6,7 near-twin      arrays: 0 spanword 1 cand|nib 2 four-hop word 3 w 4,5 twin_in 6,7 twin_prev
 // spanword: natural span (bits 0..7) | stop (bit 8) | common prefix (bits 16..23)
 
 template <bool EXT>
@@ -135,12 +135,23 @@ __device__ __forceinline__ void tile_front(const uint8_t* src, uint64_t avail, u
         const bool eq4 = k0 >= 4u;
         const bool far_enough = dist >= kDMin && dist <= 0xFFFEu;
         const bool tail = p >= tail_from;
-        const bool certain = eq4 && far_enough && !tail;
+        // a twin at most 3 positions back (runs of equal bytes): if it is visited it becomes the candidate and,
+        // being closer than 4, can never match.  Such lanes are classed "no match" optimistically; the parser
+        // verifies after the orbit that a near twin was indeed visited (else the lane goes through the exact path).
+        bool neart = false;
+        if (__ballot((twin_in | twin_prev) != 0ull) != 0ull) {          // wave-uniform: most tiles of text have no twin this close
+            const uint64_t near_in = twin_in & ~below(lane >= 3u ? lane - 3u : 0u);
+            const uint64_t near_prev = lane < 3u ? twin_prev & ~below(61u + lane) : 0ull;
+            neart = (near_in | near_prev) != 0ull && !tail;
+        }
+        const bool certain = eq4 && far_enough && !tail && !neart;
         const uint32_t nib = length_nibble(k0 < 4u ? 4u : k0);
         const uint32_t span_nat = certain ? nibble_span(nib) : 1u;
-        const bool hard_l = (eq4 && !far_enough) || tail;
+        // offset = origin - cand <= p - cand: a candidate closer than 4 bytes can never pass (offset-4) < 0xFFFB
+        // (tsq_encode.cpp:100), whatever the pair origin: such a lane is a plain "no match", not a hazard
+        const bool hard_l = (eq4 && !far_enough && dist >= 4u && !neart) || tail;
         const bool twin_l = (twin_in | twin_prev) != 0ull;
-        const uint64_t hard = __ballot(hard_l), flagged = __ballot(twin_l), certain_m = __ballot(certain);
+        const uint64_t hard = __ballot(hard_l), flagged = __ballot(twin_l), certain_m = __ballot(certain), neart_m = __ballot(neart);
         // the next four orbit hops of every lane, each as (lane or position-past-the-tile: 7 bits | halted: bit 7);
         // a hop halts when it lands on a hard lane or past the tile, and later hops repeat it.  Twin lanes do
         // not halt: the parser runs the orbit optimistically and checks the visited twins afterwards.
@@ -165,6 +176,7 @@ __device__ __forceinline__ void tile_front(const uint8_t* src, uint64_t avail, u
             rec[0] = (uint32_t)hard; rec[1] = (uint32_t)(hard >> 32);
             rec[2] = (uint32_t)flagged; rec[3] = (uint32_t)(flagged >> 32);
             rec[4] = (uint32_t)certain_m; rec[5] = (uint32_t)(certain_m >> 32);
+            rec[6] = (uint32_t)neart_m; rec[7] = (uint32_t)(neart_m >> 32);
         }
         rec[16 + 0 * 64 + lane] = span_nat | ((hard_l || twin_l) ? 256u : 0u) | (k0 << 16);
         rec[16 + 1 * 64 + lane] = cand0 | (nib << 24);
@@ -271,7 +283,9 @@ __device__ __forceinline__ void tile_parser(const uint8_t* src, uint64_t avail, 
             TSQ_ACC(4); TSQ_CNT(6, 1);
             volatile lds_u32_t* rec = recs + (t & 1u) * TileCfg::REC_WORDS;
             const uint64_t hard = (uint64_t)uniform(rec[0]) | ((uint64_t)uniform(rec[1]) << 32);
+            const uint64_t flagged_m = (uint64_t)uniform(rec[2]) | ((uint64_t)uniform(rec[3]) << 32);   // lanes with any twin
             const uint64_t certain_m = (uint64_t)uniform(rec[4]) | ((uint64_t)uniform(rec[5]) << 32);
+            const uint64_t neart_m = (uint64_t)uniform(rec[6]) | ((uint64_t)uniform(rec[7]) << 32);
             const uint32_t spanword = rec[16 + 0 * 64 + lane];
             const uint32_t hops = rec[16 + 2 * 64 + lane];
             const uint32_t lane_word = rec[16 + 1 * 64 + lane];
@@ -358,19 +372,33 @@ __device__ __forceinline__ void tile_parser(const uint8_t* src, uint64_t avail, 
                 v = ni;
             };
 
+            // exact effect of a segment on the parse state, one step per literal RUN or match (used when a run
+            // reaches a 16-byte chunk boundary inside the segment: incompressible data, runs of equal bytes)
             auto replay_segment = [&](uint64_t V) {
-                for (uint64_t m = V; m; m &= m - 1ull) {
-                    const uint32_t L = lsb64(m), q = base + L;
-                    if (!((certain_m >> L) & 1ull)) {
+                const uint64_t N = V & ~certain_m;
+                const uint32_t Le = msb64(V);
+                uint32_t L = lsb64(V);
+                while (L <= Le) {
+                    const uint32_t q = base + L;
+                    if ((N >> L) & 1ull) {                       // a run of literal bytes starting at lane L
+                        const uint32_t len = ones_from(N, L);
                         if (after_match) { run0 = q; origin_r0 = origin; odd_r0 = nsym & 1u; after_match = false; }
-                        if (q + 1u - lit_from == 16u) { nsym++; if ((nsym & 1u) == 0u) origin = q + 1u; lit_from = q + 1u; }
-                    } else {
+                        const uint32_t full = (q + len - lit_from) >> 4;            // 16-byte chunks that complete inside the run
+                        if (full) {
+                            nsym += full;
+                            if ((nsym & 1u) == 0u) origin = lit_from + 16u * full;   // the last chunk closed a pair
+                            else if (full >= 2u) origin = lit_from + 16u * (full - 1u);   // the one before it did
+                            lit_from += 16u * full;
+                        }
+                        L += len;
+                    } else {                                     // a certain match
                         const uint32_t sp = rdlane(span_nat, L);
                         if (lit_from < q) { nsym++; if ((nsym & 1u) == 0u) origin = q; }
                         nsym++;
                         if ((nsym & 1u) == 0u) origin = q + sp;
                         lit_from = q + sp;
                         after_match = true;
+                        L += sp;
                     }
                 }
             };
@@ -381,7 +409,7 @@ __device__ __forceinline__ void tile_parser(const uint8_t* src, uint64_t avail, 
                 const bool first_isN = (N >> Ls) & 1ull;
                 uint64_t r = N & (N >> 1); r &= r >> 2; r &= r >> 4; r &= r >> 8;
                 const uint32_t carried = first_isN ? base + Ls - lit_from : 0u;
-                const uint32_t first_len = first_isN ? lsb64(~(N >> Ls)) : 0u;
+                const uint32_t first_len = first_isN ? ones_from(N, Ls) : 0u;
                 if (r != 0ull || carried + first_len >= 16u) { replay_segment(V); return; }
                 if (M == 0ull) {
                     if (after_match) { run0 = base + Ls; origin_r0 = origin; odd_r0 = nsym & 1u; after_match = false; }
@@ -404,14 +432,21 @@ __device__ __forceinline__ void tile_parser(const uint8_t* src, uint64_t avail, 
                 const uint32_t seg_nsym = nsym, seg_origin = origin, seg_lit_from = lit_from;
                 bool tile_end = false;
                 if (L < 64u && !((hard >> L) & 1ull)) orbit_run4(hops, L, V);   // halts on a hard lane or past the tile
-                {
+                if (V & flagged_m) {
                     // the orbit treated twin lanes as ordinary lanes.  That is wrong for a visited lane that has a
                     // VISITED twin before it (earlier in this tile, or in the previous tile): its gathered candidate
                     // is not current.  The first such lane ends the segment; everything before it is exact.
+                    // Near-twin lanes (classed "no match" on the assumption that a twin at most 3 back is visited) are the
+                    // other way round: they are right exactly when such a twin was visited.
                     const uint64_t seen = vall | V;
-                    const bool stale = ((V >> lane) & 1ull) &&
-                                       (((tin_lo & (uint32_t)seen) | (tin_hi & (uint32_t)(seen >> 32)) |
-                                         (tpv_lo & (uint32_t)vall_prev) | (tpv_hi & (uint32_t)(vall_prev >> 32))) != 0u);
+                    const uint32_t in_lo = tin_lo & (uint32_t)seen, in_hi = tin_hi & (uint32_t)(seen >> 32);
+                    const uint32_t pv_lo = tpv_lo & (uint32_t)vall_prev, pv_hi = tpv_hi & (uint32_t)(vall_prev >> 32);
+                    const bool has_in = (in_lo | in_hi) != 0u, has_prev = (pv_lo | pv_hi) != 0u;
+                    const uint32_t nearest = in_hi ? 63u - (uint32_t)__builtin_clz(in_hi) : 31u - (uint32_t)__builtin_clz(in_lo | 1u);
+                    const uint32_t nearest_prev = pv_hi ? 63u - (uint32_t)__builtin_clz(pv_hi) : 31u - (uint32_t)__builtin_clz(pv_lo | 1u);
+                    const bool near_visited = (has_in && lane - nearest < 4u) || (has_prev && lane + 64u - nearest_prev < 4u);
+                    const bool is_near = (neart_m >> lane) & 1ull;
+                    const bool stale = ((V >> lane) & 1ull) && (is_near ? !near_visited : (has_in || has_prev));
                     const uint64_t bad = __ballot(stale);
                     if (bad) { L = lsb64(bad); V &= below(L); }
                 }
