@@ -300,20 +300,29 @@ __global__ __launch_bounds__(DecCfg::T) void dec_fast_kernel(const uint8_t* __re
             if (r.kind == 1) {
                 for (uint32_t t = 0; t < r.len; ++t) { obuf[r.out_rel + t] = sbuf[r.a + t]; srcp[r.out_rel + t] = C::RES; }
             } else if (r.kind == 2) {
+                // source bytes below `op` are final in HBM: fetch them 16 at a time (reading past `op` inside this
+                // block's own output region is harmless: those bytes are simply not used); source bytes at or
+                // beyond `op` belong to this chunk and are recorded as pointers
                 const uint32_t sa = r.a;
-                if (sa + 16u <= op && r.len <= 16u) {
-                    uint4 v;
-                    __builtin_memcpy(&v, out + sa, 16);
-                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-                    for (uint32_t t = 0; t < r.len; ++t) {
-                        obuf[r.out_rel + t] = (uint8_t)(w[t >> 2] >> (8u * (t & 3u)));
-                        srcp[r.out_rel + t] = C::RES;
-                    }
-                } else {
-                    for (uint32_t t = 0; t < r.len; ++t) {
-                        const uint32_t a = sa + t;
-                        if (a < op) { obuf[r.out_rel + t] = out[a]; srcp[r.out_rel + t] = C::RES; }
-                        else srcp[r.out_rel + t] = (uint16_t)(a - op);
+                for (uint32_t t0 = 0; t0 < r.len; t0 += 16u) {
+                    const uint32_t a0 = sa + t0;
+                    const uint32_t cnt = r.len - t0 < 16u ? r.len - t0 : 16u;
+                    if (a0 < op && a0 + 16u <= size) {
+                        TSQD_CNT(9, 1);
+                        uint4 v;
+                        __builtin_memcpy(&v, out + a0, 16);
+                        const uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+                        for (uint32_t t = 0; t < cnt; ++t) {
+                            const uint32_t a = a0 + t, q = r.out_rel + t0 + t;
+                            if (a < op) { obuf[q] = (uint8_t)(t < 8u ? lo >> (8u * t) : hi >> (8u * (t - 8u))); srcp[q] = C::RES; }
+                            else srcp[q] = (uint16_t)(a - op);
+                        }
+                    } else {
+                        for (uint32_t t = 0; t < cnt; ++t) {
+                            const uint32_t a = a0 + t, q = r.out_rel + t0 + t;
+                            if (a < op) { obuf[q] = out[a]; srcp[q] = C::RES; TSQD_CNT(10, 1); }
+                            else srcp[q] = (uint16_t)(a - op);
+                        }
                     }
                 }
             }
@@ -322,32 +331,45 @@ __global__ __launch_bounds__(DecCfg::T) void dec_fast_kernel(const uint8_t* __re
 
         TSQD_ACC(6);
         // ---------------- P6b: pointer jumping until every byte of the image is final
-        for (uint32_t round = 0; round < 20; ++round) {
-            TSQD_CNT(13, 1);
-            uint32_t pend = 0;
-            uint16_t np[C::OUTC / C::T];
-            uint8_t nv[C::OUTC / C::T];
-            uint32_t mask = 0;
+        {
+            // each thread owns image bytes q = tid + r*T and remembers which of them still hold a pointer;
+            // a round follows two links at once (all reads before all writes), so chains shrink 3x per round
+            uint32_t pending = 0;
 #pragma unroll
             for (uint32_t r = 0; r < C::OUTC / C::T; ++r) {
                 const uint32_t q = tid + r * C::T;
-                np[r] = C::RES; nv[r] = 0;
-                if (q < image_len) {
-                    const uint32_t p = srcp[q];
-                    if (p != C::RES) { np[r] = srcp[p]; nv[r] = obuf[p]; mask |= 1u << r; }
-                }
+                if (q < image_len && srcp[q] != C::RES) pending |= 1u << r;
             }
-            __syncthreads();
+            TSQD_CNT(11, __builtin_popcount(pending)); TSQD_CNT(15, image_len);
+            for (uint32_t round = 0; round < 24; ++round) {
+                if (!__syncthreads_or((int)(pending != 0u))) break;
+                TSQD_CNT(13, 1);
+                uint16_t np[C::OUTC / C::T];
+                uint8_t nv[C::OUTC / C::T];
 #pragma unroll
-            for (uint32_t r = 0; r < C::OUTC / C::T; ++r) {
-                if (mask & (1u << r)) {
-                    const uint32_t q = tid + r * C::T;
-                    if (np[r] == C::RES) obuf[q] = nv[r];
-                    else pend = 1;
-                    srcp[q] = np[r];
+                for (uint32_t r = 0; r < C::OUTC / C::T; ++r) {
+                    np[r] = C::RES; nv[r] = 0;
+                    if (pending & (1u << r)) {
+                        const uint32_t p1 = srcp[tid + r * C::T];
+                        const uint32_t p2 = srcp[p1];
+                        if (p2 == C::RES) { nv[r] = obuf[p1]; }
+                        else {
+                            const uint32_t p3 = srcp[p2];
+                            if (p3 == C::RES) nv[r] = obuf[p2];
+                            else np[r] = (uint16_t)p3;
+                        }
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (uint32_t r = 0; r < C::OUTC / C::T; ++r) {
+                    if (pending & (1u << r)) {
+                        const uint32_t q = tid + r * C::T;
+                        if (np[r] == C::RES) { obuf[q] = nv[r]; srcp[q] = C::RES; pending &= ~(1u << r); }
+                        else srcp[q] = np[r];
+                    }
                 }
             }
-            if (!__syncthreads_or((int)pend)) break;
         }
 
         TSQD_ACC(7);

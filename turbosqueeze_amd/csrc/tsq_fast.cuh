@@ -6,6 +6,7 @@
 #include "tsq_internal.h"
 #include "tsq_serial.cuh"
 #include "tsq_dec_fast.cuh"
+#include "tsq_dec_ring.cuh"
 #include "tsq_enc_fast.cuh"
 #include "tsq_enc_orbit.cuh"
 #include "tsq_enc_pipe.cuh"
@@ -51,11 +52,17 @@ inline int launch_decode_fast(tsqa_ctx* c, const uint8_t* container, uint32_t n_
 {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)DecLds::total) != hipSuccess) { c->set_error("cannot reserve %u B of LDS", DecLds::total); return TSQA_ERR_HIP; }
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DecLds::total) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(dec_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RingLds::total) != hipSuccess) {
+            c->set_error("cannot reserve LDS for the decoder");
+            return TSQA_ERR_HIP;
+        }
         attr_set = true;
     }
-    hipLaunchKernelGGL(dec_fast_kernel, dim3(n_blocks), dim3(DecCfg::T), DecLds::total, s, container, c->frames, out, status);
+    if (c->dec_variant == 2)   // the first parallel decoder (history gathered from L2), kept for A/B
+        hipLaunchKernelGGL(dec_fast_kernel, dim3(n_blocks), dim3(DecCfg::T), DecLds::total, s, container, c->frames, out, status);
+    else
+        hipLaunchKernelGGL(dec_ring_kernel, dim3(n_blocks), dim3(RingCfg::T), RingLds::total, s, container, c->frames, out, status);
     return 0;
 }
 
