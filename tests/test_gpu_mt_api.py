@@ -138,3 +138,24 @@ def test_async_chain_ordering(tsq, oracle):               # test/test.cpp:202-33
         blob = C.string_at(couts[k][0], couts[k][1].value)
         assert blob == oracle.compress(data, k & 1)
         tsq.api._libc.free(douts[k][0]); tsq.api._libc.free(couts[k][0])
+
+
+def test_cli_tool(tsq, oracle, tmp_path):                  # sample/main.cpp: `tsq c|d|b`
+    """tools/tsq_cli (C++ against include/turbosqueeze.h) compresses to the oracle's container,
+    decompresses it back, and its benchmark mode verifies its own round trip."""
+    import json
+    import subprocess
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "tsq_cli")
+    assert os.path.exists(cli), "run __graft_entry__.build() first"
+    host = tsq.synth.text((1 << 22) + 777, seed=5)
+    src, comp, back = tmp_path / "in.bin", tmp_path / "out.tsq", tmp_path / "back.bin"
+    src.write_bytes(host.tobytes())
+    for flag, ext in (([], 1), (["--no-ext"], 0)):
+        subprocess.run([cli, "c", str(src), str(comp)] + flag, check=True, timeout=300)
+        assert comp.read_bytes() == oracle.compress(host, ext)
+        subprocess.run([cli, "d", str(comp), str(back)], check=True, timeout=300)
+        assert back.read_bytes() == host.tobytes()
+    r = subprocess.run([cli, "b", "--synthetic", str(3 * (1 << 22) + 5), "--reps", "1"], check=True,
+                       timeout=300, capture_output=True, text=True)
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["output_correct"] is True and line["input_bytes"] == 3 * (1 << 22) + 5
