@@ -28,13 +28,18 @@ codec = tsq.DeviceCodec(0)
 blob = codec.compress(src, ext)
 back = codec.decompress(blob)
 assert torch.equal(back, src)
-enc = (C.c_ulonglong * 16)()
+enc = (C.c_ulonglong * 32)()
 dec = (C.c_ulonglong * 16)()
 L.tsqa_debug_stats(enc, dec)
 e = list(enc); d = list(dec)
-print(f"ENC tile pipeline block0 (cycles): FRONT wait-for-parser={e[0]} commit={e[1]} classify={e[2]} tiles={e[3]} | PARSER wait-for-front={e[4]} work={e[5]} tiles={e[6]} symbols={e[9]}")
-if e[3] and e[6]:
-    print(f"  per tile: front wait={e[0]/e[3]:.0f} commit={e[1]/e[3]:.0f} classify={e[2]/e[3]:.0f} | parser wait={e[4]/e[6]:.0f} record-load={e[7]/e[6]:.0f} orbit={e[8]/e[6]:.0f} account={e[10]/e[6]:.0f} send={e[11]/e[6]:.0f} serial={e[12]/e[6]:.0f} publish+rest={e[5]/e[6]:.0f}")
+T = max(e[15], 1)
+print(f"ENC staged pipeline block0 (tiles parsed={e[15]}, symbols={e[16]}); cycles per tile, busy = total - waited:")
+print("  SCAN    total=%.0f waited(ring)=%.0f busy=%.0f" % (e[1] / T, e[0] / T, (e[1] - e[0]) / T))
+print("  MATCH   total=%.0f waited(scan)=%.0f waited(parser)=%.0f busy=%.0f" % (e[4] / T, e[2] / T, e[3] / T, (e[4] - e[2] - e[3]) / T))
+print("  ORBIT   total=%.0f waited=%.0f busy=%.0f" % (e[7] / T, e[6] / T, (e[7] - e[6]) / T))
+print("  PARSER  total=%.0f waited(orbit)=%.0f waited(queue)=%.0f busy=%.0f" % (e[10] / T, e[8] / T, e[9] / T, (e[10] - e[8] - e[9]) / T))
+print("  BUILDER total=%.0f waited=%.0f busy=%.0f" % (e[18] / T, e[17] / T, (e[18] - e[17]) / T))
+print("  parser events per tile: flagged-checks=%.2f stale-truncations=%.2f segments=%.2f hazard-lanes=%.2f (hard %.2f) replays=%.2f" % tuple(e[k] / T for k in (22, 23, 24, 26, 27, 28)))
 print(f"  P6b detail (wave 0): init scan={d[9]} barrier waits={d[10]} read phases={d[11]} write phases={d[15]}")
 names = ["P0 stage", "P1 spec", "P2 dbl", "P3 chain", "P4 expand+scan", "P5 syms", "P6a scatter", "P6b jump", "P7 flush"]
 dt = sum(d[:9])

@@ -33,14 +33,20 @@ constexpr uint32_t kEncLds = kHashEntries;          // u8 per bucket: which lane
 
 // Instrumented builds (-DTSQ_STATS, make stats): block 0 publishes cycle and event counters.
 #ifdef TSQ_STATS
-__device__ unsigned long long g_enc_stats[16];
+__device__ unsigned long long g_enc_stats[32];
 #define TSQ_T0() unsigned long long t0_ = __builtin_amdgcn_s_memtime()
 #define TSQ_ACC(slot) do { unsigned long long t1_ = __builtin_amdgcn_s_memtime(); st_[slot] += t1_ - t0_; t0_ = t1_; } while (0)
 #define TSQ_CNT(slot, v) st_[slot] += (v)
+#define TSQ_SUB(slot) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); TSQ_ACC(slot); } while (0)
 #else
-#define TSQ_T0() do {} while (0)
+#ifdef TSQ_MARKS
+#define TSQ_ACC(slot) asm volatile("; TSQ_MARK " #slot ::: "memory")
+#else
 #define TSQ_ACC(slot) do {} while (0)
+#endif
+#define TSQ_T0() do {} while (0)
 #define TSQ_CNT(slot, v) do {} while (0)
+#define TSQ_SUB(slot) TSQ_ACC(slot)
 #endif
 
 // 16 bytes at src+at, zeros past `avail`

@@ -346,8 +346,22 @@ __device__ __forceinline__ void pipe_builder(const uint8_t* src, uint64_t avail,
         if (j0 + 1200u > kSlotSize) overflow = true;
     };
 
+#ifdef TSQ_STATS
+    unsigned long long st_[32] = {0};
+#endif
+#ifdef TSQ_STATS
+    const unsigned long long begin_ = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
-        while (__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == tail) __builtin_amdgcn_s_sleep(1);
+        if (__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == tail) {
+#ifdef TSQ_STATS
+            const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
+#endif
+            while (__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == tail) __builtin_amdgcn_s_sleep(1);
+#ifdef TSQ_STATS
+            st_[17] += __builtin_amdgcn_s_memtime() - w0_;
+#endif
+        }
         volatile lds_u32_t* it = queue + (tail % PipeCfg::Q) * PipeCfg::ITEM_WORDS;
         const uint32_t kind = uniform(it[0]);
         const uint32_t nsym_entry = uniform(it[4]);
@@ -403,6 +417,9 @@ __device__ __forceinline__ void pipe_builder(const uint8_t* src, uint64_t avail,
         if ((nsym ^ nsym_after) & ~63u) flush_batch((nsym_after & ~63u) - 64u, 64u);
         nsym = nsym_after;
     }
+#ifdef TSQ_STATS
+    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[17] = st_[17]; g_enc_stats[18] = __builtin_amdgcn_s_memtime() - begin_; }
+#endif
 
     if (overflow) { if (lane == 0) { atomicMax(status, kErrOverflow); sizes[b] = 3; } return; }
     const uint32_t rest = nsym & 63u;

@@ -1,0 +1,620 @@
+// tsq_enc_stage.cuh -- five-wave staged block encoder for gfx950 (kernel variant 0).
+//
+// A single wavefront issues about one instruction every five cycles, and the greedy parse of a block is
+// serial (tsq_encode.cpp:72-187: the position table is a function of the parse).  So the block's work
+// is cut into stages, one wavefront each, that stream 64-position tiles through records in LDS:
+//
+//   wave 0  SCAN     input words, hashes and the same-hash ("twin") masks of every tile -- everything
+//                    that does not depend on the parse; runs ahead as far as the record ring allows.
+//   wave 1  MATCH    the position table: commits the visited positions of tile t-3 (handed back by the
+//                    parser), gathers the candidates of tile t, their bytes, the common prefixes, and
+//                    classifies the lanes (certain match / certain literal / hazard).
+//   wave 2  ORBIT    the visited set from every possible entry lane of the tile, by pointer doubling.
+//   wave 3  PARSER   the serial part: picks the orbit of the actual entry lane, checks the twins it
+//                    visited, resolves hazards with exact scalar code, keeps the pair state.
+//   wave 4  BUILDER  symbol records and stream layout (tsq_enc_pipe.cuh: pipe_builder).
+//
+// Table lag.  MATCH gathers tile t from a table that holds exactly the visits of tiles <= t-3 (it does
+// the commits itself, in program order), so parser and MATCH overlap over two tiles.  What the table
+// cannot know -- a visited position of tiles t-2, t-1 or an earlier lane of t with the same hash -- is a
+// twin: SCAN finds all of them exactly (byte-per-bucket owner image in LDS, folded to 16 bits, with
+// exact hash comparison by ballot), and the parser takes the most recent VISITED twin as the
+// candidate, which is what the reference's table would hold (tsq_encode.cpp:76-79), or keeps the
+// gathered candidate when no twin was visited.
+#pragma once
+
+#include "tsq_common.cuh"
+#include "tsq_enc_pipe.cuh"
+
+namespace tsq {
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4_t lds_u32x4_t;
+
+struct StageCfg {
+    static constexpr uint32_t Q = 32;
+    static constexpr uint32_t ITEM_WORDS = 80;
+    static constexpr uint32_t RING = 128;
+    static constexpr uint32_t R = 8;                              // tile records in flight
+    static constexpr uint32_t OWN_MASK = 0xFFFFu;                 // owner image: hash folded to 16 bits
+    static constexpr uint32_t W16 = 16;                           // word offset of the uint4-per-lane input words
+    static constexpr uint32_t ARR = 16 + 256;                     // word offset of the u32-per-lane arrays
+    static constexpr uint32_t REC_WORDS = ARR + 12 * 64;
+    static constexpr uint32_t off_owner = 0;                                   // u8[65536]
+    static constexpr uint32_t off_queue = OWN_MASK + 1u;                       // u32[Q * ITEM_WORDS]
+    static constexpr uint32_t off_ring = off_queue + Q * ITEM_WORDS * 4;       // u32[RING]
+    static constexpr uint32_t off_rec = off_ring + RING * 4;                   // u32[R * REC_WORDS]
+    static constexpr uint32_t off_ctl = off_rec + R * REC_WORDS * 4;           // u32[64]
+    static constexpr uint32_t total = off_ctl + 256;
+};
+// ctl words: 0 queue head, 1 queue tail, 2 tiles scanned, 3 tiles matched, 4 tiles with orbits, 5 tiles parsed,
+//            6 stop, 16 + 2*(t&7): visited mask of tile t (lo, hi)
+// record: header words 0,1 = lanes that have an earlier twin inside the tile
+//         per-lane arrays: 0 hash  1,2 twins in this tile (earlier lanes)  3,4 twins in tile t-1  5,6 twins in tile t-2
+//                          7 spanword  8 candidate | nibble << 24  9 orbit halt  10,11 orbit mask
+// spanword: natural span (bits 0..7) | hard (8) | has a twin (9) | certain match (10) | near twin (11) | common prefix (16..23)
+enum : uint32_t { kAH = 0, kATin = 1, kATp1 = 3, kATp2 = 5, kASpan = 7, kALane = 8, kANx = 9, kAOrb = 10 };
+
+// Instrumented builds time only the spin loops (and only when they actually spin): s_memtime costs a few
+// hundred cycles, so finer timing distorts the pipeline it measures.  busy = total - waited.
+#ifdef TSQ_STATS
+#define TSQ_BEGIN() const unsigned long long begin_ = __builtin_amdgcn_s_memtime()
+#define TSQ_WAITED(slot, expr) do { const unsigned long long w0_ = __builtin_amdgcn_s_memtime(); expr; st_[slot] += __builtin_amdgcn_s_memtime() - w0_; } while (0)
+#define TSQ_TOTAL() (__builtin_amdgcn_s_memtime() - begin_)
+#else
+#define TSQ_BEGIN() do {} while (0)
+#endif
+
+__device__ __forceinline__ bool stage_ready(lds_u32_t* ctl, uint32_t word, uint32_t need)
+{
+    return uniform(__hip_atomic_load(&ctl[word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= need;
+}
+__device__ __forceinline__ bool stage_spin(lds_u32_t* ctl, uint32_t word, uint32_t need)
+{
+    for (;;) {
+        if (stage_ready(ctl, word, need)) return true;
+        if (uniform(__hip_atomic_load(&ctl[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0u) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+#ifdef TSQ_STATS
+#define stage_wait(ctl, word, need, slot) (stage_ready(ctl, word, need) || [&]() { bool ok_; TSQ_WAITED(slot, ok_ = stage_spin(ctl, word, need)); return ok_; }())
+#else
+#define stage_wait(ctl, word, need, slot) (stage_ready(ctl, word, need) || stage_spin(ctl, word, need))
+#endif
+// Publishing a record: the DS operations of one wavefront are executed by the LDS in program order, so a
+// counter stored after the record's words becomes visible after them; only the compiler has to be kept
+// from reordering (an s_waitcnt here would park the wave for a full LDS round trip per tile).
+#define TSQ_LDS_RELEASE() asm volatile("" ::: "memory")
+__device__ __forceinline__ void stage_publish(lds_u32_t* ctl, uint32_t word, uint32_t value, uint32_t lane)
+{
+    TSQ_LDS_RELEASE();
+    if (lane == 0) __hip_atomic_store(&ctl[word], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// ---------------------------------------------------------------------------------------------- SCAN
+__device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, uint32_t n, lds_u8_t* lds, uint32_t lane)
+{
+    volatile lds_u8_t* owner = lds + StageCfg::off_owner;
+    volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
+    lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
+    const uint32_t n_tiles = (n >> 6) + 3u;            // visits reach at most n + 63
+    uint32_t h_m1 = 0xFFFFFFFFu, h_m2 = 0xFFFFFFFFu, h_m3 = 0xFFFFFFFFu;   // hashes of tiles t-1 .. t-3 (per lane)
+    uint32_t id = 1;                                    // (t % 3) + 1: which of the three live tiles an owner tag names
+#ifdef TSQ_STATS
+    unsigned long long st_[32] = {0};
+#endif
+    TSQ_BEGIN();
+    for (uint32_t t = 0; t < n_tiles; ++t) {
+        // the slot of tile t-R is free once the parser has finished tile t-R+2 (it reads the words of two tiles back)
+        if (t + 3u > StageCfg::R && !stage_wait(ctl, 5, t + 3u - StageCfg::R, 0)) break;
+        const uint32_t p = (t << 6) + lane;
+        const uint4 w16 = ld128z(src, p, avail);
+        const uint32_t h = hash4(w16.x);
+        const uint32_t hf = h & StageCfg::OWN_MASK;
+        const uint32_t tag = (id << 6) | lane;          // never 0: the image starts zeroed
+        // retire the entries of tile t-3 (same id as tile t) unless a later tile has taken the bucket over
+        if (t >= 3u && ((uint32_t)owner[h_m3 & StageCfg::OWN_MASK] >> 6) == id) owner[h_m3 & StageCfg::OWN_MASK] = 0;
+        const uint32_t before = owner[hf];              // non-zero: a lane of tile t-1 or t-2 may have this hash
+        owner[hf] = (uint8_t)tag;
+        // twins inside the tile: for each lane the mask of EARLIER lanes with the same hash
+        uint64_t twin_in = 0, twins_here = 0;
+        {
+            uint64_t shared = __ballot(owner[hf] != (uint8_t)tag);
+            while (shared) {
+                const uint32_t hl = rdlane(h, lsb64(shared));
+                const uint64_t grp = __ballot(h == hl);
+                if (h == hl) twin_in = grp & below(lane);
+                twins_here |= grp & (grp - 1ull);
+                shared &= ~grp;
+            }
+        }
+        // twins in the two previous tiles
+        uint64_t twin_p1 = 0, twin_p2 = 0;
+        {
+            uint64_t maybe = __ballot(before != 0u);
+            while (maybe) {
+                const uint32_t hl = rdlane(h, lsb64(maybe));
+                const uint64_t g1 = __ballot(h_m1 == hl), g2 = __ballot(h_m2 == hl);
+                const uint64_t grp_cur = __ballot(h == hl);
+                if (h == hl) { twin_p1 = g1; twin_p2 = g2; }
+                maybe &= ~grp_cur;
+            }
+        }
+        volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
+        {
+            u32x4_t v; v.x = w16.x; v.y = w16.y; v.z = w16.z; v.w = w16.w;
+            *(volatile lds_u32x4_t*)(rec + StageCfg::W16 + lane * 4u) = v;
+        }
+        if (lane == 0) { rec[0] = (uint32_t)twins_here; rec[1] = (uint32_t)(twins_here >> 32); }
+        volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
+        arr[kAH * 64] = h;
+        arr[kATin * 64] = (uint32_t)twin_in;  arr[(kATin + 1) * 64] = (uint32_t)(twin_in >> 32);
+        arr[kATp1 * 64] = (uint32_t)twin_p1;  arr[(kATp1 + 1) * 64] = (uint32_t)(twin_p1 >> 32);
+        arr[kATp2 * 64] = (uint32_t)twin_p2;  arr[(kATp2 + 1) * 64] = (uint32_t)(twin_p2 >> 32);
+        stage_publish(ctl, 2, t + 1u, lane);
+        h_m3 = h_m2; h_m2 = h_m1; h_m1 = h;
+        id = id == 3u ? 1u : id + 1u;
+    }
+#ifdef TSQ_STATS
+    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[0] = st_[0]; g_enc_stats[1] = TSQ_TOTAL(); }
+#endif
+}
+
+// --------------------------------------------------------------------------------------------- MATCH
+template <bool EXT>
+__device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, uint32_t n, uint16_t* table, lds_u8_t* lds, uint32_t lane)
+{
+    volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
+    lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
+    constexpr uint32_t kDMin = EXT ? 128u : 64u;
+    const uint32_t tail_from = n >= 5u ? n - 5u : 0u;
+    const uint32_t n_tiles = (n >> 6) + 3u;
+    uint32_t h_m1 = 0, h_m2 = 0, h_m3 = 0;
+    uint64_t tw_m1 = 0, tw_m2 = 0, tw_m3 = 0;          // "has an earlier twin inside its tile" masks of those tiles
+#ifdef TSQ_STATS
+    unsigned long long st_[32] = {0};
+#endif
+    TSQ_BEGIN();
+    for (uint32_t t = 0; t < n_tiles; ++t) {
+        if (!stage_wait(ctl, 2, t + 1u, 2)) break;
+        volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
+        volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
+        const uint32_t h = arr[kAH * 64];
+        const u32x4_t wv = *(volatile lds_u32x4_t*)(rec + StageCfg::W16 + lane * 4u);
+        const uint4 w16 = make_uint4(wv.x, wv.y, wv.z, wv.w);
+        const uint64_t twin_in = (uint64_t)arr[kATin * 64] | ((uint64_t)arr[(kATin + 1) * 64] << 32);
+        const uint64_t twin_p1 = (uint64_t)arr[kATp1 * 64] | ((uint64_t)arr[(kATp1 + 1) * 64] << 32);
+        const uint32_t tp2_any = arr[kATp2 * 64] | arr[(kATp2 + 1) * 64];
+        const uint64_t twins_here = (uint64_t)uniform(rec[0]) | ((uint64_t)uniform(rec[1]) << 32);
+        // ---- commit tile t-3 once the parser has its visited mask: then the table holds the visits of tiles <= t-3
+        if (t >= 3u) {
+            if (!stage_wait(ctl, 5, t - 2u, 3)) break;
+            const uint32_t slot = 16u + 2u * ((t - 3u) & 7u);
+            const uint64_t vis = (uint64_t)uniform(__hip_atomic_load(&ctl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) |
+                                 ((uint64_t)uniform(__hip_atomic_load(&ctl[slot + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) << 32);
+            const uint32_t p3 = ((t - 3u) << 6) + lane;
+            // among equal hashes the highest visited lane must win: lanes with an earlier twin store afterwards, in order
+            if (((vis & ~tw_m3) >> lane) & 1ull) table[h_m3] = (uint16_t)p3;
+            uint64_t late = vis & tw_m3;
+            while (late) {
+                if (lane == lsb64(late)) table[h_m3] = (uint16_t)p3;
+                late &= late - 1ull;
+            }
+        }
+        // ---- candidates of tile t
+        const uint32_t p = (t << 6) + lane;
+        const uint32_t tv = table[h];
+        const uint32_t cand0 = candidate_of(tv, p);
+        uint32_t k0 = prefix16(w16, ld128z(src, cand0, avail));
+        if (EXT) {
+            uint32_t more = 16;
+            while (__ballot(k0 == more) != 0ull && more < 64u) {
+                if (k0 == more) k0 += prefix16(ld128z(src, (uint64_t)p + more, avail), ld128z(src, (uint64_t)cand0 + more, avail));
+                more += 16;
+            }
+        }
+        const uint32_t dist = p - cand0;
+        const bool eq4 = k0 >= 4u;
+        const bool far_enough = dist >= kDMin && dist <= 0xFFFEu;
+        const bool tail = p >= tail_from;
+        // a twin at most 3 positions back (runs of equal bytes): if it is visited it becomes the candidate and,
+        // being closer than 4, can never match.  Such lanes are classed "no match" optimistically; the parser
+        // verifies after the orbit that a near twin was indeed visited (else the lane goes through the exact path).
+        bool neart = false;
+        if (__ballot((twin_in | twin_p1) != 0ull) != 0ull) {
+            const uint64_t near_in = twin_in & ~below(lane >= 3u ? lane - 3u : 0u);
+            const uint64_t near_prev = lane < 3u ? twin_p1 & ~below(61u + lane) : 0ull;
+            neart = (near_in | near_prev) != 0ull && !tail;
+        }
+        const bool certain = eq4 && far_enough && !tail && !neart;
+        const uint32_t nib = length_nibble(k0 < 4u ? 4u : k0);
+        const uint32_t span_nat = certain ? nibble_span(nib) : 1u;
+        // offset = origin - cand <= p - cand: a candidate closer than 4 bytes can never pass (offset-4) < 0xFFFB
+        // (tsq_encode.cpp:100), whatever the pair origin: such a lane is a plain "no match", not a hazard
+        const bool hard_l = (eq4 && !far_enough && dist >= 4u && !neart) || tail;
+        const bool twin_l = (twin_in | twin_p1) != 0ull || tp2_any != 0u;
+        arr[kASpan * 64] = span_nat | (hard_l ? 0x100u : 0u) | (twin_l ? 0x200u : 0u) | (certain ? 0x400u : 0u) | (neart ? 0x800u : 0u) | (k0 << 16);
+        arr[kALane * 64] = cand0 | (nib << 24);
+        stage_publish(ctl, 3, t + 1u, lane);
+        h_m3 = h_m2; h_m2 = h_m1; h_m1 = h;
+        tw_m3 = tw_m2; tw_m2 = tw_m1; tw_m1 = twins_here;
+    }
+#ifdef TSQ_STATS
+    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[2] = st_[2]; g_enc_stats[3] = st_[3]; g_enc_stats[4] = TSQ_TOTAL(); }
+#endif
+}
+
+// --------------------------------------------------------------------------------------------- ORBIT
+__device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t lane)
+{
+    volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
+    lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
+    const uint32_t n_tiles = (n >> 6) + 3u;
+#ifdef TSQ_STATS
+    unsigned long long st_[32] = {0};
+#endif
+    TSQ_BEGIN();
+    for (uint32_t t = 0; t < n_tiles; ++t) {
+        if (!stage_wait(ctl, 3, t + 1u, 6)) break;
+        volatile lds_u32_t* arr = recs + (t % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::ARR + lane;
+        const uint32_t sw = arr[kASpan * 64];
+        // the whole orbit of every lane, by pointer doubling: `nx` = where the orbit started at this lane halts
+        // (lane, or position past the tile: 7 bits | halted: bit 7), `orb` = the lanes it visits before that.
+        // A hop halts when it lands on a hard lane or past the tile.  Twin lanes do not halt: the parser takes
+        // the orbit optimistically and checks the visited twins afterwards.
+        const uint32_t self = lane | ((sw & 0x100u) ? 0x80u : 0u);              // arriving at this lane: halts?
+        const uint32_t c = lane + (sw & 0xFFu);                                 // < 128
+        const uint32_t there = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((c & 63u) << 2), (int)self);
+        uint32_t nx = c >= 64u ? (c | 0x80u) : there;
+        uint64_t orb = 1ull << lane;
+        for (int round = 0; round < 6; ++round) {
+            if (__ballot((nx & 0x80u) == 0u) == 0ull) break;                    // every orbit has halted
+            const int at = (int)((nx & 63u) << 2);
+            const uint32_t nx2 = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)nx);
+            const uint32_t olo = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)(uint32_t)orb);
+            const uint32_t ohi = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)(uint32_t)(orb >> 32));
+            if ((nx & 0x80u) == 0u) { nx = nx2; orb |= (uint64_t)olo | ((uint64_t)ohi << 32); }
+        }
+        arr[kANx * 64] = nx;
+        arr[kAOrb * 64] = (uint32_t)orb;
+        arr[(kAOrb + 1) * 64] = (uint32_t)(orb >> 32);
+        stage_publish(ctl, 4, t + 1u, lane);
+    }
+#ifdef TSQ_STATS
+    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[6] = st_[6]; g_enc_stats[7] = TSQ_TOTAL(); }
+#endif
+}
+
+// -------------------------------------------------------------------------------------------- PARSER
+template <bool EXT>
+__device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail, uint32_t n, lds_u8_t* lds, uint32_t lane)
+{
+    volatile lds_u32_t* queue = (volatile lds_u32_t*)(lds + StageCfg::off_queue);
+    volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
+    lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
+
+    uint32_t head = 0, tail_seen = 0;  // tail_seen: last value read of the builder's progress (re-read only when the queue looks full)
+    uint32_t v = 1, nsym = 0, origin = 0, lit_from = 0;
+    bool after_match = false;
+    uint32_t run0 = 0, origin_r0 = 0, odd_r0 = 0;
+    bool done = false;
+    uint64_t vall_p1 = 0, vall_p2 = 0;   // visited lanes of the two previous tiles
+#ifdef TSQ_STATS
+    unsigned long long st_[32] = {0};
+#endif
+
+    auto slot_begin = [&]() -> volatile lds_u32_t* {
+        if (head - tail_seen >= StageCfg::Q) {
+#ifdef TSQ_STATS
+            const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
+#endif
+            while (head - tail_seen >= StageCfg::Q) {
+                tail_seen = uniform(__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (head - tail_seen >= StageCfg::Q) __builtin_amdgcn_s_sleep(2);
+            }
+#ifdef TSQ_STATS
+            st_[9] += __builtin_amdgcn_s_memtime() - w0_;
+#endif
+        }
+        return queue + (head % StageCfg::Q) * StageCfg::ITEM_WORDS;
+    };
+    auto slot_publish = [&]() {
+        TSQ_LDS_RELEASE();
+        head++;
+        __hip_atomic_store(&ctl[0], head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto push = [&](uint32_t record, uint32_t origin_if_pair_closes) {
+        volatile lds_u32_t* it = slot_begin();
+        if (lane == 0) { it[0] = kItemSym; it[4] = nsym; it[9] = record; }
+        slot_publish();
+        nsym++;
+        if ((nsym & 1u) == 0u) origin = origin_if_pair_closes;
+    };
+    // the 16 input bytes at a position of tiles t-2 .. t, from the tile records (one LDS address for the whole wave)
+    auto words_at = [&](uint32_t pos) -> uint4 {
+        const u32x4_t q = *(volatile lds_u32x4_t*)(recs + ((pos >> 6) % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::W16 + (pos & 63u) * 4u);
+        return make_uint4(q.x, q.y, q.z, q.w);
+    };
+
+    TSQ_BEGIN();
+    for (uint32_t t = 0; !done; ++t) {
+        const uint32_t base = t << 6;
+        uint64_t vall = 0;
+        if (v < base + 64u) {
+            // ---- the tile's record
+            (void)stage_wait(ctl, 4, t + 1u, 8);
+            TSQ_CNT(15, 1);
+            volatile lds_u32_t* arr = recs + (t % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::ARR + lane;
+            const uint32_t spanword = arr[kASpan * 64];
+            const uint32_t lane_word = arr[kALane * 64];
+            const uint32_t nx = arr[kANx * 64];
+            const uint32_t orb_lo = arr[kAOrb * 64], orb_hi = arr[(kAOrb + 1) * 64];
+            const uint32_t tin_lo = arr[kATin * 64], tin_hi = arr[(kATin + 1) * 64];
+            const uint32_t tp1_lo = arr[kATp1 * 64], tp1_hi = arr[(kATp1 + 1) * 64];
+            const uint32_t tp2_lo = arr[kATp2 * 64], tp2_hi = arr[(kATp2 + 1) * 64];
+            const uint64_t hard = __ballot((spanword & 0x100u) != 0u);
+            const uint64_t flagged_m = __ballot((spanword & 0x200u) != 0u);      // lanes with any twin
+            const uint64_t certain_m = __ballot((spanword & 0x400u) != 0u);
+            const uint64_t near_m = __ballot((spanword & 0x800u) != 0u);
+            const uint32_t span_nat = spanword & 0xFFu;
+            const uint32_t k0 = (spanword >> 16) & 0xFFu;
+            const uint32_t cand0 = lane_word & 0xFFFFFFu;
+
+            // The tile's symbols go to the builder as ONE item: visited lanes, which of them are matches, and the
+            // per-lane candidate|nibble words -- the builder derives literal chunks, symbol indices and pair origins
+            // from the masks.  Hazard lanes resolved below patch the masks; only the rare outcomes the masks cannot
+            // express (a literal closed in front of a match that then fails, the block tail) are pushed explicitly,
+            // after flushing what is pending.
+            uint64_t Vt = 0, Mt = 0;
+            uint32_t lw = lane_word;
+            uint32_t e_nsym = nsym, e_origin = origin, e_lit_from = lit_from;
+            auto flush_pending = [&]() {
+                if (Vt != 0ull) {
+                    volatile lds_u32_t* it = slot_begin();
+                    if (lane == 0) {
+                        it[0] = kItemSeg; it[1] = base; it[2] = (uint32_t)Vt; it[3] = (uint32_t)(Vt >> 32);
+                        it[4] = e_nsym; it[5] = e_origin; it[6] = e_lit_from;
+                        it[7] = (uint32_t)Mt; it[8] = (uint32_t)(Mt >> 32);
+                    }
+                    it[16 + lane] = lw;
+                    slot_publish();
+                }
+                Vt = 0; Mt = 0;
+            };
+
+            // exact scalar resolution of one hazard lane (hard, or with a visited twin)
+            auto resolve = [&](uint32_t L) {
+                const uint32_t i = base + L;
+                const uint64_t bit = 1ull << L;
+                uint32_t cand = rdlane(cand0, L);
+                uint32_t k = rdlane(k0, L);
+                bool twin_cand = false;
+                {
+                    // visited twins of lane L: in this tile (before L) and in the two previous tiles;
+                    // the most recent one is the candidate
+                    const uint64_t in_tile = ((uint64_t)rdlane(tin_lo, L) | ((uint64_t)rdlane(tin_hi, L) << 32)) & vall;
+                    const uint64_t in_p1 = ((uint64_t)rdlane(tp1_lo, L) | ((uint64_t)rdlane(tp1_hi, L) << 32)) & vall_p1;
+                    const uint64_t in_p2 = ((uint64_t)rdlane(tp2_lo, L) | ((uint64_t)rdlane(tp2_hi, L) << 32)) & vall_p2;
+                    if (in_tile | in_p1 | in_p2) {
+                        if (in_tile) cand = base + msb64(in_tile);
+                        else if (in_p1) cand = base - 64u + msb64(in_p1);
+                        else cand = base - 128u + msb64(in_p2);
+                        k = uniform(prefix16(words_at(i), words_at(cand)));
+                        twin_cand = true;
+                    }
+                }
+                const bool e4 = k >= 4u;
+                vall |= bit;
+                auto new_run = [&]() { after_match = false; run0 = i; origin_r0 = origin; odd_r0 = nsym & 1u; lit_from = i; v = i + 1u; };
+                bool pend = false;                               // a pending literal [lit_from, i) closes in front of the match
+                if (after_match) {
+                    if (!(i < n - 5u && e4 && offset_ok(origin - cand))) {               // tsq_encode.cpp:170
+                        after_match = false;
+                        if (!(i < n)) { done = true; return; }                           // tsq_encode.cpp:173
+                        Vt |= bit;
+                        new_run();
+                        return;
+                    }
+                } else {
+                    const uint32_t f = (i - 1u - run0) >> 5;
+                    const uint32_t o_ref = f == 0u ? origin_r0 : (odd_r0 ? run0 + 32u * f - 16u : run0 + 32u * f);
+                    const bool ok = e4 && offset_ok(o_ref - cand);                        // tsq_encode.cpp:80,100
+                    if (i < n && !ok) {
+                        Vt |= bit;
+                        v = i + 1u;
+                        if (v - lit_from == 16u) { nsym++; if ((nsym & 1u) == 0u) origin = v; lit_from = v; }   // a full chunk: the builder sees it in the masks
+                        return;
+                    }
+                    pend = i > lit_from;                                                 // tsq_encode.cpp:103-118
+                    if (!(i < n)) {                                                      // tsq_encode.cpp:120
+                        flush_pending();
+                        if (pend) { push(rec_literal(lit_from, i - lit_from), i); lit_from = i; }
+                        done = true;
+                        return;
+                    }
+                }
+                if (EXT && twin_cand) {
+                    while (k >= 16u && k < 64u && (k & 15u) == 0u) {
+                        const uint32_t add = uniform(prefix16(ld128z(src, (uint64_t)i + k, avail), ld128z(src, (uint64_t)cand + k, avail)));
+                        k += add;
+                        if (add < 16u) break;
+                    }
+                }
+                // the pair origin the match sees: after the pending literal, if there is one
+                const uint32_t nsym1 = nsym + (pend ? 1u : 0u);
+                const uint32_t origin1 = (pend && (nsym1 & 1u) == 0u) ? i : origin;
+                const uint32_t room = origin1 - cand;
+                if (k > room) k = room - 1u;
+                if (k < 4u || !offset_ok(room)) {
+                    // the literal was closed and the match then fails: the masks cannot say that
+                    if (pend) {
+                        flush_pending();
+                        push(rec_literal(lit_from, i - lit_from), i);
+                        lit_from = i;
+                        e_nsym = nsym; e_origin = origin; e_lit_from = lit_from;
+                    }
+                    Vt |= bit;
+                    new_run();
+                    return;
+                }
+                const uint32_t m = length_nibble(k);
+                const uint32_t ni = i + nibble_span(m);
+                nsym = nsym1 + 1u;
+                origin = (nsym & 1u) == 0u ? ni : origin1;
+                Vt |= bit; Mt |= bit;
+                lw = lane == L ? (cand | (m << 24)) : lw;
+                after_match = true;
+                lit_from = ni;
+                v = ni;
+            };
+
+            // exact effect of a segment on the parse state, one step per literal RUN or match (used when a run
+            // reaches a 16-byte chunk boundary inside the segment: incompressible data, runs of equal bytes)
+            auto replay_segment = [&](uint64_t V) {
+                const uint64_t N = V & ~certain_m;
+                const uint32_t Le = msb64(V);
+                uint32_t L = lsb64(V);
+                while (L <= Le) {
+                    const uint32_t q = base + L;
+                    if ((N >> L) & 1ull) {                       // a run of literal bytes starting at lane L
+                        const uint32_t len = ones_from(N, L);
+                        if (after_match) { run0 = q; origin_r0 = origin; odd_r0 = nsym & 1u; after_match = false; }
+                        const uint32_t full = (q + len - lit_from) >> 4;            // 16-byte chunks that complete inside the run
+                        if (full) {
+                            nsym += full;
+                            if ((nsym & 1u) == 0u) origin = lit_from + 16u * full;   // the last chunk closed a pair
+                            else if (full >= 2u) origin = lit_from + 16u * (full - 1u);   // the one before it did
+                            lit_from += 16u * full;
+                        }
+                        L += len;
+                    } else {                                     // a certain match
+                        const uint32_t sp = rdlane(span_nat, L);
+                        if (lit_from < q) { nsym++; if ((nsym & 1u) == 0u) origin = q; }
+                        nsym++;
+                        if ((nsym & 1u) == 0u) origin = q + sp;
+                        lit_from = q + sp;
+                        after_match = true;
+                        L += sp;
+                    }
+                }
+            };
+            auto account_segment = [&](uint64_t V) {
+                if (V == 0ull) return;
+                const uint64_t M = V & certain_m, N = V & ~certain_m;
+                const uint32_t Ls = lsb64(V), Le = msb64(V);
+                const bool first_isN = (N >> Ls) & 1ull;
+                uint64_t r = N & (N >> 1); r &= r >> 2; r &= r >> 4; r &= r >> 8;
+                const uint32_t carried = first_isN ? base + Ls - lit_from : 0u;
+                const uint32_t first_len = first_isN ? ones_from(N, Ls) : 0u;
+                if (r != 0ull || carried + first_len >= 16u) { TSQ_CNT(28, 1); replay_segment(V); return; }
+                if (M == 0ull) {
+                    if (after_match) { run0 = base + Ls; origin_r0 = origin; odd_r0 = nsym & 1u; after_match = false; }
+                    return;
+                }
+                const uint32_t pre = (!first_isN && lit_from < base + Ls) ? 1u : 0u;
+                const uint32_t Lm = msb64(M);
+                const uint32_t endm = base + Lm + rdlane(span_nat, Lm);
+                nsym += (uint32_t)__builtin_popcountll(M) + (uint32_t)__builtin_popcountll(M & (N << 1)) + pre;
+                origin = (nsym & 1u) ? base + Lm : endm;
+                lit_from = endm;
+                if (Le == Lm) { after_match = true; }
+                else { after_match = false; run0 = endm; origin_r0 = origin; odd_r0 = nsym & 1u; }
+            };
+
+            // twins visited in the two previous tiles: fixed for the whole tile
+            const bool prev_hit = ((tp1_lo & (uint32_t)vall_p1) | (tp1_hi & (uint32_t)(vall_p1 >> 32)) |
+                                   (tp2_lo & (uint32_t)vall_p2) | (tp2_hi & (uint32_t)(vall_p2 >> 32))) != 0u;
+            uint32_t L = v - base;
+            while (!done) {
+                uint64_t V = 0;
+                if (Vt == 0ull) { e_nsym = nsym; e_origin = origin; e_lit_from = lit_from; }
+                if (L < 64u && !((hard >> L) & 1ull)) {                          // the orbit from L: halts on a hard lane or past the tile
+                    V = (uint64_t)rdlane(orb_lo, L) | ((uint64_t)rdlane(orb_hi, L) << 32);
+                    L = rdlane(nx, L) & 0x7Fu;
+                }
+                if (V & flagged_m) {
+                    // the orbit treated twin lanes as ordinary lanes.  That is wrong for a visited lane that has a
+                    // VISITED twin before it (earlier in this tile, or in the two previous tiles): its gathered
+                    // candidate is not current.  The first such lane ends the segment; everything before it is exact.
+                    const uint64_t seen = vall | V;
+                    const uint32_t in_lo = tin_lo & (uint32_t)seen, in_hi = tin_hi & (uint32_t)(seen >> 32);
+                    bool stale = (in_lo | in_hi) != 0u || prev_hit;
+                    if (V & near_m) {
+                        // near-twin lanes (classed "no match" on the assumption that a twin at most 3 back is visited) are
+                        // the other way round: they are right exactly when such a twin was visited
+                        const uint32_t pv_lo = tp1_lo & (uint32_t)vall_p1, pv_hi = tp1_hi & (uint32_t)(vall_p1 >> 32);
+                        const bool has_in = (in_lo | in_hi) != 0u, has_prev = (pv_lo | pv_hi) != 0u;
+                        const uint32_t nearest = in_hi ? 63u - (uint32_t)__builtin_clz(in_hi) : 31u - (uint32_t)__builtin_clz(in_lo | 1u);
+                        const uint32_t nearest_prev = pv_hi ? 63u - (uint32_t)__builtin_clz(pv_hi) : 31u - (uint32_t)__builtin_clz(pv_lo | 1u);
+                        const bool near_visited = (has_in && lane - nearest < 4u) || (has_prev && lane + 64u - nearest_prev < 4u);
+                        if ((spanword & 0x800u) != 0u) stale = !near_visited;
+                    }
+                    const uint64_t bad = __ballot(stale) & V;
+                    if (bad) { L = lsb64(bad); V &= below(L); TSQ_CNT(23, 1); }
+                    TSQ_CNT(22, 1);
+                }
+                TSQ_CNT(24, 1);
+                account_segment(V);
+                Vt |= V; Mt |= V & certain_m;
+                vall |= V;
+                if (L >= 64u) { v = base + L; break; }
+                TSQ_CNT(26, 1); TSQ_CNT(27, ((hard >> L) & 1ull) ? 1 : 0);
+                resolve(L);
+                L = v - base;
+            }
+            flush_pending();
+        }
+        // ---- hand the tile's visited mask to MATCH (it commits the table) and move on
+        if (lane == 0) {
+            const uint32_t slot = 16u + 2u * (t & 7u);
+            __hip_atomic_store(&ctl[slot], (uint32_t)vall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&ctl[slot + 1u], (uint32_t)(vall >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        stage_publish(ctl, 5, t + 1u, lane);
+        vall_p2 = vall_p1; vall_p1 = vall;
+    }
+#ifdef TSQ_STATS
+    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[8] = st_[8]; g_enc_stats[9] = st_[9]; g_enc_stats[10] = TSQ_TOTAL(); g_enc_stats[15] = st_[15]; g_enc_stats[16] = nsym; for (int q = 22; q < 29; ++q) g_enc_stats[q] = st_[q]; }
+#endif
+    if (lane == 0) __hip_atomic_store(&ctl[6], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    {
+        volatile lds_u32_t* it = slot_begin();
+        if (lane == 0) { it[0] = kItemEnd; it[4] = nsym; }
+        slot_publish();
+    }
+}
+
+template <bool EXT>
+__global__ __launch_bounds__(320) void enc_stage_kernel(const uint8_t* __restrict__ in, uint64_t n_total, uint64_t readable,
+                                                        uint8_t* __restrict__ slots, uint32_t* __restrict__ sizes,
+                                                        uint16_t* __restrict__ tables, int32_t* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t stage_lds[];
+    const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u;
+    const uint32_t role = uniform(threadIdx.x >> 6);
+    const uint64_t start = (uint64_t)b << kBlockBits;
+    const uint64_t avail = readable - start;
+    const uint32_t n = n_total - start < kBlockSize ? (uint32_t)(n_total - start) : kBlockSize;
+    const uint8_t* src = in + start;
+    uint8_t* out = slots + (size_t)b * kSlotSize;
+    uint16_t* table = tables + (size_t)b * kHashEntries;
+
+    {   // tsqInit (tsq_context.cpp:77-80), all five waves
+        uint4* t4 = reinterpret_cast<uint4*>(table);
+        for (uint32_t k = threadIdx.x; k < kHashEntries * 2 / 16; k += 320) t4[k] = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x < 64) reinterpret_cast<uint32_t*>(stage_lds + StageCfg::off_ctl)[threadIdx.x] = 0;
+        uint4* o4 = reinterpret_cast<uint4*>(stage_lds + StageCfg::off_owner);          // owner image: no valid entries
+        for (uint32_t k = threadIdx.x; k < (StageCfg::OWN_MASK + 1u) / 16; k += 320) o4[k] = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x == 0) { out[0] = (uint8_t)n; out[1] = (uint8_t)(n >> 8); out[2] = (uint8_t)(n >> 16); }
+    }
+    __syncthreads();
+    lds_u8_t* lds3 = (lds_u8_t*)stage_lds;
+    if (role == 0) stage_scan(src, avail, n, lds3, lane);
+    else if (role == 1) stage_match<EXT>(src, avail, n, table, lds3, lane);
+    else if (role == 2) stage_orbit(n, lds3, lane);
+    else if (role == 3) stage_parser<EXT>(src, avail, n, lds3, lane);
+    else pipe_builder<StageCfg>(src, avail, out, lds3, lane, b, sizes, status);
+}
+
+}  // namespace tsq

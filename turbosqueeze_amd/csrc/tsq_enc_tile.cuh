@@ -29,7 +29,7 @@ struct TileCfg {
     static constexpr uint32_t Q = 32;
     static constexpr uint32_t ITEM_WORDS = 80;
     static constexpr uint32_t RING = 128;
-    static constexpr uint32_t REC_WORDS = 16 + 8 * 64;         // header + 8 per-lane arrays
+    static constexpr uint32_t REC_WORDS = 16 + 10 * 64;        // header + 10 per-lane arrays
     static constexpr uint32_t off_owner = 0;                                   // u8[kHashEntries]
     static constexpr uint32_t off_queue = kHashEntries;                        // u32[Q * ITEM_WORDS]
     static constexpr uint32_t off_ring = off_queue + Q * ITEM_WORDS * 4;       // u32[RING]
@@ -39,7 +39,7 @@ struct TileCfg {
 };
 // ctl words: 0 queue head, 1 queue tail, 2 tiles classified, 3 tiles parsed, 4 stop,
 //            8 + 2*(t&3): visited mask of tile t (lo, hi)
-// record header: 0,1 hard  2,3 flagged  4,5 certain  6,7 near-twin      arrays: 0 spanword 1 cand|nib 2 four-hop word 3 w 4,5 twin_in 6,7 twin_prev
+// record header: 0,1 hard  2,3 flagged  4,5 certain  6,7 near-twin      arrays: 0 spanword 1 cand|nib 2 orbit halt 3 w 4,5 twin_in 6,7 twin_prev 8,9 orbit mask
 // spanword: natural span (bits 0..7) | stop (bit 8) | common prefix (bits 16..23)
 
 template <bool EXT>
@@ -56,7 +56,7 @@ __device__ __forceinline__ void tile_front(const uint8_t* src, uint64_t avail, u
     uint64_t twins_m1 = 0, twins_m2 = 0;                // in-tile "has an earlier twin" masks of those tiles
 
 #ifdef TSQ_STATS
-    unsigned long long st_[16] = {0};
+    unsigned long long st_[32] = {0};
 #endif
     TSQ_T0();
     for (uint32_t t = 0; t < n_tiles; ++t) {
@@ -92,6 +92,7 @@ __device__ __forceinline__ void tile_front(const uint8_t* src, uint64_t avail, u
         const uint4 w16 = ld128z(src, p, avail);
         const uint32_t w = w16.x;
         const uint32_t h = hash4(w);
+        TSQ_SUB(16);
         const uint32_t tag = 0x80u | ((t & 1u) << 6) | lane;        // bit 7: a valid entry (the image starts zeroed)
         // retire the entries of tile t-2 (unless tile t-1 has taken the bucket over): only tile t-1's stay valid
         if (t >= 2u && (owner[h_m2] & 0xC0u) == (0x80u | ((t & 1u) << 6))) owner[h_m2] = 0;
@@ -99,6 +100,7 @@ __device__ __forceinline__ void tile_front(const uint8_t* src, uint64_t avail, u
         owner[h] = (uint8_t)tag;
         const uint32_t tv = table[h];
         const uint32_t cand0 = candidate_of(tv, p);
+        TSQ_SUB(17);
         uint32_t k0 = prefix16(w16, ld128z(src, cand0, avail));
         if (EXT) {
             uint32_t more = 16;
@@ -107,6 +109,7 @@ __device__ __forceinline__ void tile_front(const uint8_t* src, uint64_t avail, u
                 more += 16;
             }
         }
+        TSQ_SUB(18);
         // twins inside the tile: for each lane the mask of EARLIER lanes with the same hash
         uint64_t twin_in = 0, twins_here = 0;
         {
@@ -131,6 +134,7 @@ __device__ __forceinline__ void tile_front(const uint8_t* src, uint64_t avail, u
                 maybe &= ~grp_cur;
             }
         }
+        TSQ_SUB(19);
         const uint32_t dist = p - cand0;
         const bool eq4 = k0 >= 4u;
         const bool far_enough = dist >= kDMin && dist <= 0xFFFEu;
@@ -152,25 +156,28 @@ __device__ __forceinline__ void tile_front(const uint8_t* src, uint64_t avail, u
         const bool hard_l = (eq4 && !far_enough && dist >= 4u && !neart) || tail;
         const bool twin_l = (twin_in | twin_prev) != 0ull;
         const uint64_t hard = __ballot(hard_l), flagged = __ballot(twin_l), certain_m = __ballot(certain), neart_m = __ballot(neart);
-        // the next four orbit hops of every lane, each as (lane or position-past-the-tile: 7 bits | halted: bit 7);
-        // a hop halts when it lands on a hard lane or past the tile, and later hops repeat it.  Twin lanes do
-        // not halt: the parser runs the orbit optimistically and checks the visited twins afterwards.
-        uint32_t hops;
+        // the whole orbit of every lane, by pointer doubling: `nx` = where the orbit started at this lane halts
+        // (lane, or position past the tile: 7 bits | halted: bit 7), `orb` = the lanes it visits before that.
+        // A hop halts when it lands on a hard lane or past the tile.  Twin lanes do not halt: the parser takes
+        // the orbit optimistically and checks the visited twins afterwards.
+        uint32_t nx;
+        uint64_t orb = 1ull << lane;
         {
             const uint32_t self = lane | (hard_l ? 0x80u : 0u);                    // arriving at this lane: halts?
-            auto land = [&](uint32_t c) -> uint32_t {                               // c = lane + span, < 128
-                const uint32_t there = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((c & 63u) << 2), (int)self);
-                return c >= 64u ? (c | 0x80u) : there;
-            };
-            const uint32_t h1 = land(lane + span_nat);                              // hop 1 of this lane
-            auto next_of = [&](uint32_t hv) -> uint32_t {                           // hop 1 of the lane a hop value points at
-                const uint32_t there = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((hv & 63u) << 2), (int)h1);
-                return (hv & 0x80u) ? hv : there;
-            };
-            const uint32_t h2 = next_of(h1), h3 = next_of(h2), h4 = next_of(h3);
-            hops = h1 | (h2 << 8) | (h3 << 16) | (h4 << 24);
+            const uint32_t c = lane + span_nat;                                     // < 128
+            const uint32_t there = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((c & 63u) << 2), (int)self);
+            nx = c >= 64u ? (c | 0x80u) : there;
+            for (int round = 0; round < 6; ++round) {
+                if (__ballot((nx & 0x80u) == 0u) == 0ull) break;                    // every orbit has halted
+                const int at = (int)((nx & 63u) << 2);
+                const uint32_t nx2 = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)nx);
+                const uint32_t olo = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)(uint32_t)orb);
+                const uint32_t ohi = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)(uint32_t)(orb >> 32));
+                if ((nx & 0x80u) == 0u) { nx = nx2; orb |= (uint64_t)olo | ((uint64_t)ohi << 32); }
+            }
         }
 
+        TSQ_SUB(20);
         volatile lds_u32_t* rec = recs + (t & 1u) * TileCfg::REC_WORDS;
         if (lane == 0) {
             rec[0] = (uint32_t)hard; rec[1] = (uint32_t)(hard >> 32);
@@ -180,21 +187,24 @@ __device__ __forceinline__ void tile_front(const uint8_t* src, uint64_t avail, u
         }
         rec[16 + 0 * 64 + lane] = span_nat | ((hard_l || twin_l) ? 256u : 0u) | (k0 << 16);
         rec[16 + 1 * 64 + lane] = cand0 | (nib << 24);
-        rec[16 + 2 * 64 + lane] = hops;
+        rec[16 + 2 * 64 + lane] = nx;
         rec[16 + 3 * 64 + lane] = w;
         rec[16 + 4 * 64 + lane] = (uint32_t)twin_in;
         rec[16 + 5 * 64 + lane] = (uint32_t)(twin_in >> 32);
         rec[16 + 6 * 64 + lane] = (uint32_t)twin_prev;
         rec[16 + 7 * 64 + lane] = (uint32_t)(twin_prev >> 32);
+        rec[16 + 8 * 64 + lane] = (uint32_t)orb;
+        rec[16 + 9 * 64 + lane] = (uint32_t)(orb >> 32);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(&ctl[2], t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // (prefetching the next tile's input words here was measured and does not pay: loads and stores retire in
         //  order, so the prefetch either delays this tile's gathers or makes the next step wait for the commit stores)
         h_m2 = h_m1; h_m1 = h;
         twins_m2 = twins_m1; twins_m1 = twins_here;
-        TSQ_ACC(2);
+        TSQ_ACC(21);
 #ifdef TSQ_STATS
-        if (blockIdx.x == 0 && lane == 0 && (t & 1023u) == 1023u) { g_enc_stats[0] = st_[0]; g_enc_stats[1] = st_[1]; g_enc_stats[2] = st_[2]; g_enc_stats[3] = t + 1; }
+        st_[2] = st_[16] + st_[17] + st_[18] + st_[19] + st_[20] + st_[21];
+        if (blockIdx.x == 0 && lane == 0 && (t & 1023u) == 1023u) { g_enc_stats[0] = st_[0]; g_enc_stats[1] = st_[1]; g_enc_stats[2] = st_[2]; g_enc_stats[3] = t + 1; for (int q = 16; q < 22; ++q) g_enc_stats[q] = st_[q]; }
 #endif
     }
 }
@@ -270,7 +280,7 @@ __device__ __forceinline__ void tile_parser(const uint8_t* src, uint64_t avail, 
     };
 
 #ifdef TSQ_STATS
-    unsigned long long st_[16] = {0};
+    unsigned long long st_[32] = {0};
 #endif
     TSQ_T0();
     for (uint32_t t = 0; !done; ++t) {
@@ -287,7 +297,8 @@ __device__ __forceinline__ void tile_parser(const uint8_t* src, uint64_t avail, 
             const uint64_t certain_m = (uint64_t)uniform(rec[4]) | ((uint64_t)uniform(rec[5]) << 32);
             const uint64_t neart_m = (uint64_t)uniform(rec[6]) | ((uint64_t)uniform(rec[7]) << 32);
             const uint32_t spanword = rec[16 + 0 * 64 + lane];
-            const uint32_t hops = rec[16 + 2 * 64 + lane];
+            const uint32_t nx = rec[16 + 2 * 64 + lane];
+            const uint32_t orb_lo = rec[16 + 8 * 64 + lane], orb_hi = rec[16 + 9 * 64 + lane];
             const uint32_t lane_word = rec[16 + 1 * 64 + lane];
             const uint32_t w = rec[16 + 3 * 64 + lane];
             const uint32_t tin_lo = rec[16 + 4 * 64 + lane], tin_hi = rec[16 + 5 * 64 + lane];
@@ -410,7 +421,7 @@ __device__ __forceinline__ void tile_parser(const uint8_t* src, uint64_t avail, 
                 uint64_t r = N & (N >> 1); r &= r >> 2; r &= r >> 4; r &= r >> 8;
                 const uint32_t carried = first_isN ? base + Ls - lit_from : 0u;
                 const uint32_t first_len = first_isN ? ones_from(N, Ls) : 0u;
-                if (r != 0ull || carried + first_len >= 16u) { replay_segment(V); return; }
+                if (r != 0ull || carried + first_len >= 16u) { TSQ_CNT(28, 1); replay_segment(V); return; }
                 if (M == 0ull) {
                     if (after_match) { run0 = base + Ls; origin_r0 = origin; odd_r0 = nsym & 1u; after_match = false; }
                     return;
@@ -431,7 +442,10 @@ __device__ __forceinline__ void tile_parser(const uint8_t* src, uint64_t avail, 
                 uint64_t V = 0;
                 const uint32_t seg_nsym = nsym, seg_origin = origin, seg_lit_from = lit_from;
                 bool tile_end = false;
-                if (L < 64u && !((hard >> L) & 1ull)) orbit_run4(hops, L, V);   // halts on a hard lane or past the tile
+                if (L < 64u && !((hard >> L) & 1ull)) {                          // the orbit from L: halts on a hard lane or past the tile
+                    V = (uint64_t)rdlane(orb_lo, L) | ((uint64_t)rdlane(orb_hi, L) << 32);
+                    L = rdlane(nx, L) & 0x7Fu;
+                }
                 if (V & flagged_m) {
                     // the orbit treated twin lanes as ordinary lanes.  That is wrong for a visited lane that has a
                     // VISITED twin before it (earlier in this tile, or in the previous tile): its gathered candidate
@@ -448,9 +462,11 @@ __device__ __forceinline__ void tile_parser(const uint8_t* src, uint64_t avail, 
                     const bool is_near = (neart_m >> lane) & 1ull;
                     const bool stale = ((V >> lane) & 1ull) && (is_near ? !near_visited : (has_in || has_prev));
                     const uint64_t bad = __ballot(stale);
-                    if (bad) { L = lsb64(bad); V &= below(L); }
+                    if (bad) { L = lsb64(bad); V &= below(L); TSQ_CNT(23, 1); }
+                    TSQ_CNT(22, 1);
                 }
                 tile_end = L >= 64u;
+                TSQ_CNT(24, 1); TSQ_CNT(25, V != 0ull ? 1 : 0);
                 TSQ_ACC(8);
                 account_segment(V);
                 TSQ_ACC(10);
@@ -458,6 +474,7 @@ __device__ __forceinline__ void tile_parser(const uint8_t* src, uint64_t avail, 
                 TSQ_ACC(11);
                 vall |= V;
                 if (tile_end) { v = base + L; break; }
+                TSQ_CNT(26, 1); TSQ_CNT(27, ((hard >> L) & 1ull) ? 1 : 0);
                 visit_serial(L);
                 TSQ_ACC(12);
                 L = v - base;
@@ -475,7 +492,7 @@ __device__ __forceinline__ void tile_parser(const uint8_t* src, uint64_t avail, 
     }
 #ifdef TSQ_STATS
     TSQ_ACC(5);
-    if (blockIdx.x == 0 && lane == 0) { for (int q = 4; q < 13; ++q) g_enc_stats[q] = st_[q]; g_enc_stats[9] = nsym; }
+    if (blockIdx.x == 0 && lane == 0) { for (int q = 4; q < 13; ++q) g_enc_stats[q] = st_[q]; g_enc_stats[9] = nsym; for (int q = 22; q < 29; ++q) g_enc_stats[q] = st_[q]; }
 #endif
     if (lane == 0) __hip_atomic_store(&ctl[4], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     {

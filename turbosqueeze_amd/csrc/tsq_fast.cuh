@@ -11,6 +11,7 @@
 #include "tsq_enc_orbit.cuh"
 #include "tsq_enc_pipe.cuh"
 #include "tsq_enc_tile.cuh"
+#include "tsq_enc_stage.cuh"
 
 namespace tsq {
 
@@ -21,7 +22,8 @@ inline int launch_encode_fast(tsqa_ctx* c, const uint8_t* in, size_t n, size_t r
     if (rc) return rc;
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[8] = {reinterpret_cast<const void*>(enc_tile_kernel<true>), reinterpret_cast<const void*>(enc_tile_kernel<false>),
+        const void* fns[10] = {reinterpret_cast<const void*>(enc_stage_kernel<true>), reinterpret_cast<const void*>(enc_stage_kernel<false>),
+                              reinterpret_cast<const void*>(enc_tile_kernel<true>), reinterpret_cast<const void*>(enc_tile_kernel<false>),
                               reinterpret_cast<const void*>(enc_fast_kernel<true>), reinterpret_cast<const void*>(enc_fast_kernel<false>),
                               reinterpret_cast<const void*>(enc_orbit_kernel<true>), reinterpret_cast<const void*>(enc_orbit_kernel<false>),
                               reinterpret_cast<const void*>(enc_pipe_kernel<true>), reinterpret_cast<const void*>(enc_pipe_kernel<false>)};
@@ -41,9 +43,12 @@ inline int launch_encode_fast(tsqa_ctx* c, const uint8_t* in, size_t n, size_t r
     } else if (c->enc_variant == 4) {   // two-wave pipeline: parser + builder (kept for A/B)
         if (ext) hipLaunchKernelGGL(enc_pipe_kernel<true>, dim3(nb), dim3(128), PipeCfg::total, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
         else     hipLaunchKernelGGL(enc_pipe_kernel<false>, dim3(nb), dim3(128), PipeCfg::total, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
-    } else {                            // three-wave tile pipeline: front + parser + builder
+    } else if (c->enc_variant == 5) {   // three-wave tile pipeline: front + parser + builder (kept for A/B)
         if (ext) hipLaunchKernelGGL(enc_tile_kernel<true>, dim3(nb), dim3(192), TileCfg::total, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
         else     hipLaunchKernelGGL(enc_tile_kernel<false>, dim3(nb), dim3(192), TileCfg::total, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
+    } else {                            // five-wave staged pipeline: scan + match + orbit + parser + builder
+        if (ext) hipLaunchKernelGGL(enc_stage_kernel<true>, dim3(nb), dim3(320), StageCfg::total, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
+        else     hipLaunchKernelGGL(enc_stage_kernel<false>, dim3(nb), dim3(320), StageCfg::total, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
     }
     return 0;
 }
