@@ -61,7 +61,15 @@ enum : uint32_t { kAH = 0, kATin = 1, kATp1 = 3, kATp2 = 5, kASpan = 7, kALane =
 #define TSQ_BEGIN() const unsigned long long begin_ = __builtin_amdgcn_s_memtime()
 #define TSQ_WAITED(slot, expr) do { const unsigned long long w0_ = __builtin_amdgcn_s_memtime(); expr; st_[slot] += __builtin_amdgcn_s_memtime() - w0_; } while (0)
 #define TSQ_TOTAL() (__builtin_amdgcn_s_memtime() - begin_)
+// one timed region per build (-DTSQ_REGION=k): two s_memtime per pass through the region, calibrated by region 0 (empty)
+#ifndef TSQ_REGION
+#define TSQ_REGION -1
+#endif
+#define REG_BEGIN(k) unsigned long long r0_##k = 0; if (k == TSQ_REGION) r0_##k = __builtin_amdgcn_s_memtime()
+#define REG_END(k) do { if (k == TSQ_REGION) { st_[11] += __builtin_amdgcn_s_memtime() - r0_##k; st_[12] += 1; } } while (0)
 #else
+#define REG_BEGIN(k) do {} while (0)
+#define REG_END(k) do {} while (0)
 #define TSQ_BEGIN() do {} while (0)
 #endif
 
@@ -172,9 +180,25 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
     const uint32_t n_tiles = (n >> 6) + 3u;
     uint32_t h_m1 = 0, h_m2 = 0, h_m3 = 0;
     uint64_t tw_m1 = 0, tw_m2 = 0, tw_m3 = 0;          // "has an earlier twin inside its tile" masks of those tiles
+    uint32_t tv_pre = 0;                               // table entries of the NEXT tile, gathered while this tile's candidate bytes fly
+    bool pre = false;
 #ifdef TSQ_STATS
     unsigned long long st_[32] = {0};
 #endif
+    // commit a tile once the parser has its visited mask: hashes and in-tile twin mask of that tile
+    auto commit = [&](uint32_t tc, uint32_t hc, uint64_t twc) {
+        const uint32_t slot = 16u + 2u * (tc & 7u);
+        const uint64_t vis = (uint64_t)uniform(__hip_atomic_load(&ctl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) |
+                             ((uint64_t)uniform(__hip_atomic_load(&ctl[slot + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) << 32);
+        const uint32_t pc = (tc << 6) + lane;
+        // among equal hashes the highest visited lane must win: lanes with an earlier twin store afterwards, in order
+        if (((vis & ~twc) >> lane) & 1ull) table[hc] = (uint16_t)pc;
+        uint64_t late = vis & twc;
+        while (late) {
+            if (lane == lsb64(late)) table[hc] = (uint16_t)pc;
+            late &= late - 1ull;
+        }
+    };
     TSQ_BEGIN();
     for (uint32_t t = 0; t < n_tiles; ++t) {
         if (!stage_wait(ctl, 2, t + 1u, 2)) break;
@@ -187,26 +211,29 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         const uint64_t twin_p1 = (uint64_t)arr[kATp1 * 64] | ((uint64_t)arr[(kATp1 + 1) * 64] << 32);
         const uint32_t tp2_any = arr[kATp2 * 64] | arr[(kATp2 + 1) * 64];
         const uint64_t twins_here = (uint64_t)uniform(rec[0]) | ((uint64_t)uniform(rec[1]) << 32);
-        // ---- commit tile t-3 once the parser has its visited mask: then the table holds the visits of tiles <= t-3
-        if (t >= 3u) {
-            if (!stage_wait(ctl, 5, t - 2u, 3)) break;
-            const uint32_t slot = 16u + 2u * ((t - 3u) & 7u);
-            const uint64_t vis = (uint64_t)uniform(__hip_atomic_load(&ctl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) |
-                                 ((uint64_t)uniform(__hip_atomic_load(&ctl[slot + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) << 32);
-            const uint32_t p3 = ((t - 3u) << 6) + lane;
-            // among equal hashes the highest visited lane must win: lanes with an earlier twin store afterwards, in order
-            if (((vis & ~tw_m3) >> lane) & 1ull) table[h_m3] = (uint16_t)p3;
-            uint64_t late = vis & tw_m3;
-            while (late) {
-                if (lane == lsb64(late)) table[h_m3] = (uint16_t)p3;
-                late &= late - 1ull;
+        // ---- the table must hold exactly the visits of tiles <= t-3 when tile t is gathered
+        uint32_t tv;
+        if (pre) tv = tv_pre;                                   // gathered during the previous iteration
+        else {
+            if (t >= 3u) {
+                if (!stage_wait(ctl, 5, t - 2u, 3)) break;
+                commit(t - 3u, h_m3, tw_m3);
             }
+            tv = table[h];
         }
-        // ---- candidates of tile t
+        // ---- candidates of tile t: their bytes are gathered now ...
         const uint32_t p = (t << 6) + lane;
-        const uint32_t tv = table[h];
         const uint32_t cand0 = candidate_of(tv, p);
-        uint32_t k0 = prefix16(w16, ld128z(src, cand0, avail));
+        const uint4 cb = ld128z(src, cand0, avail);
+        // ... and while they fly, the next tile's table entries, if the parser is far enough (it has finished tile t-2)
+        pre = false;
+        if (t + 1u < n_tiles && stage_ready(ctl, 2, t + 2u) && (t < 2u || stage_ready(ctl, 5, t - 1u))) {
+            const uint32_t h_next = (recs + ((t + 1u) % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::ARR + lane)[kAH * 64];
+            if (t >= 2u) commit(t - 2u, h_m2, tw_m2);
+            tv_pre = table[h_next];
+            pre = true;
+        }
+        uint32_t k0 = prefix16(w16, cb);
         if (EXT) {
             uint32_t more = 16;
             while (__ballot(k0 == more) != 0ull && more < 64u) {
@@ -286,7 +313,34 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
 #endif
 }
 
+// ---- uniform (SGPR) flag arithmetic for the parser wave.  Flags are 0/1 integers and every select is an explicit
+//      s_cmp + s_cselect pair: left to itself the compiler keeps uniform booleans as 64-bit lane masks, selects through
+//      `s_and_b64 exec` triples and converts them to integers through a VGPR (v_cndmask + v_readfirstlane, ~30 cycles).
+__device__ __forceinline__ uint32_t s_sel(uint32_t c, uint32_t a, uint32_t b)
+{ uint32_t d; asm("s_cmp_lg_u32 %1, 0\n\ts_cselect_b32 %0, %2, %3" : "=s"(d) : "s"(c), "s"(a), "s"(b) : "scc"); return d; }
+__device__ __forceinline__ uint64_t s_sel64(uint32_t c, uint64_t a, uint64_t b)
+{ uint64_t d; asm("s_cmp_lg_u32 %1, 0\n\ts_cselect_b64 %0, %2, %3" : "=s"(d) : "s"(c), "s"(a), "s"(b) : "scc"); return d; }
+__device__ __forceinline__ uint32_t s_nz64(uint64_t x)
+{ uint32_t d; asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(d) : "s"(x) : "scc"); return d; }
+__device__ __forceinline__ uint32_t s_nz(uint32_t x)
+{ uint32_t d; asm("s_min_u32 %0, %1, 1" : "=s"(d) : "s"(x) : "scc"); return d; }
+__device__ __forceinline__ uint32_t s_lt(uint32_t a, uint32_t b)
+{ uint32_t d; asm("s_cmp_lt_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(d) : "s"(a), "s"(b) : "scc"); return d; }
+__device__ __forceinline__ uint32_t s_ge(uint32_t a, uint32_t b)
+{ uint32_t d; asm("s_cmp_ge_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(d) : "s"(a), "s"(b) : "scc"); return d; }
+__device__ __forceinline__ uint32_t s_eq(uint32_t a, uint32_t b)
+{ uint32_t d; asm("s_cmp_eq_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(d) : "s"(a), "s"(b) : "scc"); return d; }
+__device__ __forceinline__ uint32_t s_offset_ok(uint32_t offset)          // tsq_encode.cpp:100
+{ uint32_t d; asm("s_add_u32 %0, %1, -4\n\ts_cmp_lt_u32 %0, 0xfffb\n\ts_cselect_b32 %0, 1, 0" : "=&s"(d) : "s"(offset) : "scc"); return d; }
+__device__ __forceinline__ uint32_t s_msb64(uint64_t x)                   // x != 0
+{ uint32_t d; asm("s_flbit_i32_b64 %0, %1\n\ts_xor_b32 %0, %0, 63" : "=s"(d) : "s"(x) : "scc"); return d; }
+__device__ __forceinline__ uint32_t s_lsb64(uint64_t x)                   // x != 0
+{ uint32_t d; asm("s_ff1_i32_b64 %0, %1" : "=s"(d) : "s"(x)); return d; }
+
 // -------------------------------------------------------------------------------------------- PARSER
+// All parse state lives in uniform 32-bit integers (flags as 0/1, not bool: a bool that crosses a branch
+// becomes a 64-bit lane mask and costs VALU round trips), and the common paths are straight-line selects:
+// for a single wavefront a uniform branch costs more than the few instructions it skips.
 template <bool EXT>
 __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail, uint32_t n, lds_u8_t* lds, uint32_t lane)
 {
@@ -296,9 +350,9 @@ __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail,
 
     uint32_t head = 0, tail_seen = 0;  // tail_seen: last value read of the builder's progress (re-read only when the queue looks full)
     uint32_t v = 1, nsym = 0, origin = 0, lit_from = 0;
-    bool after_match = false;
-    uint32_t run0 = 0, origin_r0 = 0, odd_r0 = 0;
-    bool done = false;
+    uint32_t am = 0;                   // 1 right after a match (tsq_encode.cpp:160-187), 0 inside a literal run
+    uint32_t run0 = 0, origin_r0 = 0, odd_r0 = 0;   // where the current literal run started, the pair origin and symbol parity then
+    uint32_t done = 0;
     uint64_t vall_p1 = 0, vall_p2 = 0;   // visited lanes of the two previous tiles
 #ifdef TSQ_STATS
     unsigned long long st_[32] = {0};
@@ -322,7 +376,7 @@ __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail,
     auto slot_publish = [&]() {
         TSQ_LDS_RELEASE();
         head++;
-        __hip_atomic_store(&ctl[0], head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_store(&ctl[0], head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     auto push = [&](uint32_t record, uint32_t origin_if_pair_closes) {
         volatile lds_u32_t* it = slot_begin();
@@ -338,11 +392,13 @@ __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail,
     };
 
     TSQ_BEGIN();
-    for (uint32_t t = 0; !done; ++t) {
+    for (uint32_t t = 0; done == 0u; ++t) {
         const uint32_t base = t << 6;
         uint64_t vall = 0;
         if (v < base + 64u) {
             // ---- the tile's record
+            REG_BEGIN(0); REG_END(0);
+            REG_BEGIN(1);
             (void)stage_wait(ctl, 4, t + 1u, 8);
             TSQ_CNT(15, 1);
             volatile lds_u32_t* arr = recs + (t % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::ARR + lane;
@@ -354,9 +410,11 @@ __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail,
             const uint32_t tp1_lo = arr[kATp1 * 64], tp1_hi = arr[(kATp1 + 1) * 64];
             const uint32_t tp2_lo = arr[kATp2 * 64], tp2_hi = arr[(kATp2 + 1) * 64];
             const uint64_t hard = __ballot((spanword & 0x100u) != 0u);
-            const uint64_t flagged_m = __ballot((spanword & 0x200u) != 0u);      // lanes with any twin
             const uint64_t certain_m = __ballot((spanword & 0x400u) != 0u);
             const uint64_t near_m = __ballot((spanword & 0x800u) != 0u);
+            // a twin visited in the two previous tiles: fixed for the whole tile (kept per lane, it joins the in-tile test)
+            const uint32_t prev_hit = (tp1_lo & (uint32_t)vall_p1) | (tp1_hi & (uint32_t)(vall_p1 >> 32)) |
+                                      (tp2_lo & (uint32_t)vall_p2) | (tp2_hi & (uint32_t)(vall_p2 >> 32));
             const uint32_t span_nat = spanword & 0xFFu;
             const uint32_t k0 = (spanword >> 16) & 0xFFu;
             const uint32_t cand0 = lane_word & 0xFFFFFFu;
@@ -372,101 +430,21 @@ __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail,
             auto flush_pending = [&]() {
                 if (Vt != 0ull) {
                     volatile lds_u32_t* it = slot_begin();
-                    if (lane == 0) {
-                        it[0] = kItemSeg; it[1] = base; it[2] = (uint32_t)Vt; it[3] = (uint32_t)(Vt >> 32);
-                        it[4] = e_nsym; it[5] = e_origin; it[6] = e_lit_from;
-                        it[7] = (uint32_t)Mt; it[8] = (uint32_t)(Mt >> 32);
-                    }
+                    // the nine header words, one per lane, in one store
+                    uint32_t hv = kItemSeg;
+                    asm volatile("v_writelane_b32 %0, %1, 1" : "+v"(hv) : "s"(base));
+                    asm volatile("v_writelane_b32 %0, %1, 2" : "+v"(hv) : "s"((uint32_t)Vt));
+                    asm volatile("v_writelane_b32 %0, %1, 3" : "+v"(hv) : "s"((uint32_t)(Vt >> 32)));
+                    asm volatile("v_writelane_b32 %0, %1, 4" : "+v"(hv) : "s"(e_nsym));
+                    asm volatile("v_writelane_b32 %0, %1, 5" : "+v"(hv) : "s"(e_origin));
+                    asm volatile("v_writelane_b32 %0, %1, 6" : "+v"(hv) : "s"(e_lit_from));
+                    asm volatile("v_writelane_b32 %0, %1, 7" : "+v"(hv) : "s"((uint32_t)Mt));
+                    asm volatile("v_writelane_b32 %0, %1, 8" : "+v"(hv) : "s"((uint32_t)(Mt >> 32)));
+                    if (lane < 9u) it[lane] = hv;
                     it[16 + lane] = lw;
                     slot_publish();
                 }
                 Vt = 0; Mt = 0;
-            };
-
-            // exact scalar resolution of one hazard lane (hard, or with a visited twin)
-            auto resolve = [&](uint32_t L) {
-                const uint32_t i = base + L;
-                const uint64_t bit = 1ull << L;
-                uint32_t cand = rdlane(cand0, L);
-                uint32_t k = rdlane(k0, L);
-                bool twin_cand = false;
-                {
-                    // visited twins of lane L: in this tile (before L) and in the two previous tiles;
-                    // the most recent one is the candidate
-                    const uint64_t in_tile = ((uint64_t)rdlane(tin_lo, L) | ((uint64_t)rdlane(tin_hi, L) << 32)) & vall;
-                    const uint64_t in_p1 = ((uint64_t)rdlane(tp1_lo, L) | ((uint64_t)rdlane(tp1_hi, L) << 32)) & vall_p1;
-                    const uint64_t in_p2 = ((uint64_t)rdlane(tp2_lo, L) | ((uint64_t)rdlane(tp2_hi, L) << 32)) & vall_p2;
-                    if (in_tile | in_p1 | in_p2) {
-                        if (in_tile) cand = base + msb64(in_tile);
-                        else if (in_p1) cand = base - 64u + msb64(in_p1);
-                        else cand = base - 128u + msb64(in_p2);
-                        k = uniform(prefix16(words_at(i), words_at(cand)));
-                        twin_cand = true;
-                    }
-                }
-                const bool e4 = k >= 4u;
-                vall |= bit;
-                auto new_run = [&]() { after_match = false; run0 = i; origin_r0 = origin; odd_r0 = nsym & 1u; lit_from = i; v = i + 1u; };
-                bool pend = false;                               // a pending literal [lit_from, i) closes in front of the match
-                if (after_match) {
-                    if (!(i < n - 5u && e4 && offset_ok(origin - cand))) {               // tsq_encode.cpp:170
-                        after_match = false;
-                        if (!(i < n)) { done = true; return; }                           // tsq_encode.cpp:173
-                        Vt |= bit;
-                        new_run();
-                        return;
-                    }
-                } else {
-                    const uint32_t f = (i - 1u - run0) >> 5;
-                    const uint32_t o_ref = f == 0u ? origin_r0 : (odd_r0 ? run0 + 32u * f - 16u : run0 + 32u * f);
-                    const bool ok = e4 && offset_ok(o_ref - cand);                        // tsq_encode.cpp:80,100
-                    if (i < n && !ok) {
-                        Vt |= bit;
-                        v = i + 1u;
-                        if (v - lit_from == 16u) { nsym++; if ((nsym & 1u) == 0u) origin = v; lit_from = v; }   // a full chunk: the builder sees it in the masks
-                        return;
-                    }
-                    pend = i > lit_from;                                                 // tsq_encode.cpp:103-118
-                    if (!(i < n)) {                                                      // tsq_encode.cpp:120
-                        flush_pending();
-                        if (pend) { push(rec_literal(lit_from, i - lit_from), i); lit_from = i; }
-                        done = true;
-                        return;
-                    }
-                }
-                if (EXT && twin_cand) {
-                    while (k >= 16u && k < 64u && (k & 15u) == 0u) {
-                        const uint32_t add = uniform(prefix16(ld128z(src, (uint64_t)i + k, avail), ld128z(src, (uint64_t)cand + k, avail)));
-                        k += add;
-                        if (add < 16u) break;
-                    }
-                }
-                // the pair origin the match sees: after the pending literal, if there is one
-                const uint32_t nsym1 = nsym + (pend ? 1u : 0u);
-                const uint32_t origin1 = (pend && (nsym1 & 1u) == 0u) ? i : origin;
-                const uint32_t room = origin1 - cand;
-                if (k > room) k = room - 1u;
-                if (k < 4u || !offset_ok(room)) {
-                    // the literal was closed and the match then fails: the masks cannot say that
-                    if (pend) {
-                        flush_pending();
-                        push(rec_literal(lit_from, i - lit_from), i);
-                        lit_from = i;
-                        e_nsym = nsym; e_origin = origin; e_lit_from = lit_from;
-                    }
-                    Vt |= bit;
-                    new_run();
-                    return;
-                }
-                const uint32_t m = length_nibble(k);
-                const uint32_t ni = i + nibble_span(m);
-                nsym = nsym1 + 1u;
-                origin = (nsym & 1u) == 0u ? ni : origin1;
-                Vt |= bit; Mt |= bit;
-                lw = lane == L ? (cand | (m << 24)) : lw;
-                after_match = true;
-                lit_from = ni;
-                v = ni;
             };
 
             // exact effect of a segment on the parse state, one step per literal RUN or match (used when a run
@@ -479,7 +457,7 @@ __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail,
                     const uint32_t q = base + L;
                     if ((N >> L) & 1ull) {                       // a run of literal bytes starting at lane L
                         const uint32_t len = ones_from(N, L);
-                        if (after_match) { run0 = q; origin_r0 = origin; odd_r0 = nsym & 1u; after_match = false; }
+                        if (am) { run0 = q; origin_r0 = origin; odd_r0 = nsym & 1u; am = 0; }
                         const uint32_t full = (q + len - lit_from) >> 4;            // 16-byte chunks that complete inside the run
                         if (full) {
                             nsym += full;
@@ -494,88 +472,194 @@ __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail,
                         nsym++;
                         if ((nsym & 1u) == 0u) origin = q + sp;
                         lit_from = q + sp;
-                        after_match = true;
+                        am = 1;
                         L += sp;
                     }
                 }
             };
-            auto account_segment = [&](uint64_t V) {
-                if (V == 0ull) return;
-                const uint64_t M = V & certain_m, N = V & ~certain_m;
-                const uint32_t Ls = lsb64(V), Le = msb64(V);
-                const bool first_isN = (N >> Ls) & 1ull;
-                uint64_t r = N & (N >> 1); r &= r >> 2; r &= r >> 4; r &= r >> 8;
-                const uint32_t carried = first_isN ? base + Ls - lit_from : 0u;
-                const uint32_t first_len = first_isN ? ones_from(N, Ls) : 0u;
-                if (r != 0ull || carried + first_len >= 16u) { TSQ_CNT(28, 1); replay_segment(V); return; }
-                if (M == 0ull) {
-                    if (after_match) { run0 = base + Ls; origin_r0 = origin; odd_r0 = nsym & 1u; after_match = false; }
-                    return;
-                }
-                const uint32_t pre = (!first_isN && lit_from < base + Ls) ? 1u : 0u;
-                const uint32_t Lm = msb64(M);
-                const uint32_t endm = base + Lm + rdlane(span_nat, Lm);
-                nsym += (uint32_t)__builtin_popcountll(M) + (uint32_t)__builtin_popcountll(M & (N << 1)) + pre;
-                origin = (nsym & 1u) ? base + Lm : endm;
-                lit_from = endm;
-                if (Le == Lm) { after_match = true; }
-                else { after_match = false; run0 = endm; origin_r0 = origin; odd_r0 = nsym & 1u; }
-            };
-
-            // twins visited in the two previous tiles: fixed for the whole tile
-            const bool prev_hit = ((tp1_lo & (uint32_t)vall_p1) | (tp1_hi & (uint32_t)(vall_p1 >> 32)) |
-                                   (tp2_lo & (uint32_t)vall_p2) | (tp2_hi & (uint32_t)(vall_p2 >> 32))) != 0u;
             uint32_t L = v - base;
-            while (!done) {
-                uint64_t V = 0;
-                if (Vt == 0ull) { e_nsym = nsym; e_origin = origin; e_lit_from = lit_from; }
-                if (L < 64u && !((hard >> L) & 1ull)) {                          // the orbit from L: halts on a hard lane or past the tile
-                    V = (uint64_t)rdlane(orb_lo, L) | ((uint64_t)rdlane(orb_hi, L) << 32);
-                    L = rdlane(nx, L) & 0x7Fu;
+            REG_END(1);
+            // Costs that shape this loop (one wavefront, measured: tools/micro/issue_rate.hip): ALU instruction 4.5 cycles,
+            // branch ~20 cycles taken OR NOT, a VALU result read by the SALU (readlane, ballot) +20 cycles.  So: selects
+            // instead of branches, rare cases folded into one test, lane reads batched.
+            while (done == 0u) {
+                REG_BEGIN(2);
+                const uint32_t L0 = L;                                           // < 64
+                {
+                    const uint32_t fresh = s_nz64(Vt) ^ 1u;
+                    e_nsym = s_sel(fresh, nsym, e_nsym); e_origin = s_sel(fresh, origin, e_origin); e_lit_from = s_sel(fresh, lit_from, e_lit_from);
                 }
-                if (V & flagged_m) {
-                    // the orbit treated twin lanes as ordinary lanes.  That is wrong for a visited lane that has a
-                    // VISITED twin before it (earlier in this tile, or in the two previous tiles): its gathered
-                    // candidate is not current.  The first such lane ends the segment; everything before it is exact.
-                    const uint64_t seen = vall | V;
-                    const uint32_t in_lo = tin_lo & (uint32_t)seen, in_hi = tin_hi & (uint32_t)(seen >> 32);
-                    bool stale = (in_lo | in_hi) != 0u || prev_hit;
-                    if (V & near_m) {
-                        // near-twin lanes (classed "no match" on the assumption that a twin at most 3 back is visited) are
-                        // the other way round: they are right exactly when such a twin was visited
-                        const uint32_t pv_lo = tp1_lo & (uint32_t)vall_p1, pv_hi = tp1_hi & (uint32_t)(vall_p1 >> 32);
-                        const bool has_in = (in_lo | in_hi) != 0u, has_prev = (pv_lo | pv_hi) != 0u;
-                        const uint32_t nearest = in_hi ? 63u - (uint32_t)__builtin_clz(in_hi) : 31u - (uint32_t)__builtin_clz(in_lo | 1u);
-                        const uint32_t nearest_prev = pv_hi ? 63u - (uint32_t)__builtin_clz(pv_hi) : 31u - (uint32_t)__builtin_clz(pv_lo | 1u);
-                        const bool near_visited = (has_in && lane - nearest < 4u) || (has_prev && lane + 64u - nearest_prev < 4u);
-                        if ((spanword & 0x800u) != 0u) stale = !near_visited;
-                    }
-                    const uint64_t bad = __ballot(stale) & V;
-                    if (bad) { L = lsb64(bad); V &= below(L); TSQ_CNT(23, 1); }
-                    TSQ_CNT(22, 1);
+                // the orbit from L0: halts on a hard lane or past the tile (nothing at all if L0 itself is hard)
+                const uint32_t o_lo = rdlane(orb_lo, L0), o_hi = rdlane(orb_hi, L0), o_nx = rdlane(nx, L0);
+                const uint32_t entry_ok = ((uint32_t)(hard >> L0) & 1u) ^ 1u;
+                uint64_t V = s_sel64(entry_ok, (uint64_t)o_lo | ((uint64_t)o_hi << 32), 0ull);
+                L = s_sel(entry_ok, o_nx & 0x7Fu, L0);
+                // the orbit treated twin lanes as ordinary lanes.  That is wrong for a visited lane that has a VISITED
+                // twin before it (earlier in this tile, or in the two previous tiles): its gathered candidate is not
+                // current.  The first such lane ends the segment; everything before it is exact.
+                const uint64_t seen = vall | V;
+                const uint32_t in_lo = tin_lo & (uint32_t)seen, in_hi = tin_hi & (uint32_t)(seen >> 32);
+                uint64_t bad = __ballot((in_lo | in_hi | prev_hit) != 0u) & V;
+                if (__builtin_expect(s_nz64(V & near_m), 0)) {
+                    // near-twin lanes (classed "no match" on the assumption that a twin at most 3 back is visited) are
+                    // the other way round: they are right exactly when such a twin was visited
+                    uint32_t a_lo = in_lo, a_hi = in_hi;
+                    asm volatile("; near twins" : "+v"(a_lo), "+v"(a_hi));             // keeps this block's arithmetic out of the tile prologue
+                    const uint32_t pv_lo = tp1_lo & (uint32_t)vall_p1, pv_hi = tp1_hi & (uint32_t)(vall_p1 >> 32);
+                    const bool has_in = (a_lo | a_hi) != 0u, has_prev = (pv_lo | pv_hi) != 0u;
+                    const uint32_t nearest = a_hi ? 63u - (uint32_t)__builtin_clz(a_hi) : 31u - (uint32_t)__builtin_clz(a_lo | 1u);
+                    const uint32_t nearest_prev = pv_hi ? 63u - (uint32_t)__builtin_clz(pv_hi) : 31u - (uint32_t)__builtin_clz(pv_lo | 1u);
+                    const bool near_visited = (has_in && lane - nearest < 4u) || (has_prev && lane + 64u - nearest_prev < 4u);
+                    bad = ((bad & ~near_m) | (near_m & ~__ballot(near_visited))) & V;
+                }
+                {
+                    const uint32_t trunc = s_nz64(bad);
+                    const uint32_t Lb = s_lsb64(bad | (1ull << 63));
+                    V = s_sel64(trunc, V & ((1ull << Lb) - 1ull), V);
+                    L = s_sel(trunc, Lb, L);
+                    TSQ_CNT(23, trunc);
                 }
                 TSQ_CNT(24, 1);
-                account_segment(V);
-                Vt |= V; Mt |= V & certain_m;
+                REG_END(2);
+                REG_BEGIN(3);
+                // ---- the segment's effect on the parse state, O(1) from its masks.  `dsym` symbols close (matches and
+                //      the literal runs in front of them); the state afterwards hangs on the last match.
+                const uint64_t M = V & certain_m, N = V ^ M;
+                {
+                    const uint32_t nonempty = s_nz64(V), has_m = s_nz64(M);
+                    const uint32_t Le = s_msb64(V | 1ull), Lm = s_msb64(M | 1ull);
+                    const uint32_t first_isN = (uint32_t)(N >> L0) & 1u;                // L0 is the lowest lane of V
+                    uint64_t r = N & (N >> 1); r &= r >> 2; r &= r >> 4; r &= r >> 8;     // a literal run of 16 or more inside
+                    const uint32_t run_end = base + s_sel(has_m, s_lsb64(M | (1ull << 63)), Le + 1u);
+                    const uint32_t chunk = s_ge(run_end - lit_from, 16u) & first_isN;     // the entry run completes a 16-byte chunk
+                    if (__builtin_expect(s_nz64(r) | chunk, 0)) { TSQ_CNT(28, 1); replay_segment(V); }
+                    else {
+                        const uint32_t e_pos = base + L0, lm_pos = base + Lm, endm = lm_pos + rdlane(span_nat, Lm);
+                        const uint32_t last_m = s_eq(Le, Lm) & has_m;
+                        const uint32_t pre = s_lt(lit_from, e_pos) & (first_isN ^ 1u);      // a pending literal closes in front of an entry match
+                        const uint32_t dsym = (uint32_t)__builtin_popcountll(M) + (uint32_t)__builtin_popcountll(M & (N << 1)) + pre;
+                        const uint32_t nsym_n = nsym + s_sel(has_m, dsym, 0u);
+                        const uint32_t origin_n = s_sel(has_m, s_sel(nsym_n & 1u, lm_pos, endm), origin);
+                        const uint32_t new_run = s_sel(has_m, last_m ^ 1u, am & nonempty);   // a literal run starts inside / at the entry of the segment
+                        run0 = s_sel(new_run, s_sel(has_m, endm, e_pos), run0);
+                        origin_r0 = s_sel(new_run, origin_n, origin_r0);
+                        odd_r0 = s_sel(new_run, nsym_n & 1u, odd_r0);
+                        lit_from = s_sel(has_m, endm, lit_from);
+                        am = s_sel(nonempty, last_m, am);
+                        nsym = nsym_n;
+                        origin = origin_n;
+                    }
+                }
+                REG_END(3);
+                Vt |= V; Mt |= M;
                 vall |= V;
                 if (L >= 64u) { v = base + L; break; }
+                REG_BEGIN(4);
                 TSQ_CNT(26, 1); TSQ_CNT(27, ((hard >> L) & 1ull) ? 1 : 0);
-                resolve(L);
+                {
+                    // ---- exact scalar resolution of one hazard lane (hard, or with a visited twin)
+                    const uint32_t i = base + L;
+                    const uint64_t bit = 1ull << L;
+                    uint32_t cand = rdlane(cand0, L);
+                    uint32_t k = rdlane(k0, L);
+                    uint32_t twin_cand = 0;
+                    {
+                        // visited twins of lane L: in this tile (before L) and in the two previous tiles;
+                        // the most recent one is the candidate
+                        const uint64_t in_tile = ((uint64_t)rdlane(tin_lo, L) | ((uint64_t)rdlane(tin_hi, L) << 32)) & vall;
+                        const uint64_t in_p1 = ((uint64_t)rdlane(tp1_lo, L) | ((uint64_t)rdlane(tp1_hi, L) << 32)) & vall_p1;
+                        const uint64_t in_p2 = ((uint64_t)rdlane(tp2_lo, L) | ((uint64_t)rdlane(tp2_hi, L) << 32)) & vall_p2;
+                        if (in_tile | in_p1 | in_p2) {
+                            const uint64_t pick = in_tile ? in_tile : in_p1 ? in_p1 : in_p2;
+                            const uint32_t back = in_tile ? 0u : in_p1 ? 64u : 128u;
+                            cand = base - back + msb64(pick);
+                            k = uniform(prefix16(words_at(i), words_at(cand)));
+                            twin_cand = 1;
+                            TSQ_CNT(17, in_tile ? 1 : 0); TSQ_CNT(18, (!in_tile && in_p1) ? 1 : 0); TSQ_CNT(19, (!in_tile && !in_p1) ? 1 : 0);
+                        }
+                    }
+                    vall |= bit;
+                    const uint32_t e4 = s_ge(k, 4u);
+                    const uint32_t f = (i - 1u - run0) >> 5;
+                    const uint32_t o_ref = s_sel(f, s_sel(odd_r0, run0 + 32u * f - 16u, run0 + 32u * f), origin_r0);
+                    // the first test (tsq_encode.cpp:80,100 in a literal run; :170 right after a match)
+                    const uint32_t pass = e4 & s_sel(am, s_lt(i, n - 5u) & s_offset_ok(origin - cand), s_offset_ok(o_ref - cand));
+                    if (__builtin_expect(!(i < n), 0)) {
+                        // the end of the block (tsq_encode.cpp:120,173)
+                        if (am == 0u || pass) {
+                            flush_pending();
+                            if (am == 0u && i > lit_from) { push(rec_literal(lit_from, i - lit_from), i); lit_from = i; }
+                        }
+                        am = 0;
+                        done = 1;
+                    } else if (pass == 0u) {
+                        // no match here: the lane is a literal byte, either the first of a new run or one more of the current one
+                        // (where a full 16-byte chunk may close: the builder sees that in the masks)
+                        Vt |= bit;
+                        v = i + 1u;
+                        const uint32_t full = s_eq(v - lit_from, 16u) & (am ^ 1u);
+                        run0 = s_sel(am, i, run0); origin_r0 = s_sel(am, origin, origin_r0); odd_r0 = s_sel(am, nsym & 1u, odd_r0);
+                        nsym += full;
+                        origin = s_sel(full & ((nsym & 1u) ^ 1u), v, origin);
+                        lit_from = s_sel(am, i, s_sel(full, v, lit_from));
+                        am = 0;
+                    } else {
+                        const uint32_t pend = s_lt(lit_from, i) & (am ^ 1u);   // a pending literal closes in front of the match (tsq_encode.cpp:103-118)
+                        if (EXT && twin_cand) {
+                            while (k >= 16u && k < 64u && (k & 15u) == 0u) {
+                                const uint32_t add = uniform(prefix16(ld128z(src, (uint64_t)i + k, avail), ld128z(src, (uint64_t)cand + k, avail)));
+                                k += add;
+                                if (add < 16u) break;
+                            }
+                        }
+                        // the pair origin the match sees: after the pending literal, if there is one
+                        const uint32_t nsym1 = nsym + pend;
+                        const uint32_t origin1 = s_sel(pend & ((nsym1 & 1u) ^ 1u), i, origin);
+                        const uint32_t room = origin1 - cand;
+                        k = s_sel(s_lt(room, k), room - 1u, k);
+                        if (__builtin_expect(s_lt(k, 4u) | (s_offset_ok(room) ^ 1u), 0)) {
+                            // the literal was closed and the match then fails: the masks cannot say that
+                            if (pend) {
+                                flush_pending();
+                                push(rec_literal(lit_from, i - lit_from), i);
+                                e_nsym = nsym; e_origin = origin; e_lit_from = i;
+                            }
+                            Vt |= bit;
+                            am = 0; run0 = i; origin_r0 = origin; odd_r0 = nsym & 1u; lit_from = i; v = i + 1u;
+                        } else {
+                            const uint32_t m = length_nibble(k);
+                            const uint32_t ni = i + nibble_span(m);
+                            nsym = nsym1 + 1u;
+                            origin = s_sel(nsym & 1u, origin1, ni);
+                            TSQ_CNT(21, 1);
+                            Vt |= bit; Mt |= bit;
+                            lw = lane == L ? (cand | (m << 24)) : lw;
+                            am = 1;
+                            lit_from = ni;
+                            v = ni;
+                        }
+                    }
+                }
                 L = v - base;
+                REG_END(4);
+                if (L >= 64u) break;
             }
+            REG_BEGIN(5);
             flush_pending();
+            REG_END(5);
         }
         // ---- hand the tile's visited mask to MATCH (it commits the table) and move on
-        if (lane == 0) {
+        REG_BEGIN(6);
+        {
             const uint32_t slot = 16u + 2u * (t & 7u);
-            __hip_atomic_store(&ctl[slot], (uint32_t)vall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&ctl[slot + 1u], (uint32_t)(vall >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane < 2u) __hip_atomic_store(&ctl[slot + lane], lane ? (uint32_t)(vall >> 32) : (uint32_t)vall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         stage_publish(ctl, 5, t + 1u, lane);
         vall_p2 = vall_p1; vall_p1 = vall;
+        REG_END(6);
     }
 #ifdef TSQ_STATS
-    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[8] = st_[8]; g_enc_stats[9] = st_[9]; g_enc_stats[10] = TSQ_TOTAL(); g_enc_stats[15] = st_[15]; g_enc_stats[16] = nsym; for (int q = 22; q < 29; ++q) g_enc_stats[q] = st_[q]; }
+    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[8] = st_[8]; g_enc_stats[9] = st_[9]; g_enc_stats[10] = TSQ_TOTAL(); g_enc_stats[11] = st_[11]; g_enc_stats[12] = st_[12]; g_enc_stats[15] = st_[15]; g_enc_stats[16] = nsym; for (int q = 22; q < 29; ++q) g_enc_stats[q] = st_[q]; g_enc_stats[29] = st_[17]; g_enc_stats[30] = st_[18]; g_enc_stats[31] = st_[19]; g_enc_stats[20] = st_[20]; g_enc_stats[21] = st_[21]; }
 #endif
     if (lane == 0) __hip_atomic_store(&ctl[6], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     {
