@@ -8,7 +8,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAMES = ["(empty: timer cost)", "wait+loads+prologue", "orbit+check", "account", "resolve", "flush", "publish"]
+NAMES = {0: "(empty: timer cost)", 1: "P wait+loads+prologue", 2: "P orbit+check", 3: "P account", 4: "P resolve", 5: "P flush", 6: "P publish",
+         10: "M wait scan + record loads", 11: "M wait parser + commit", 12: "M table gather", 13: "M candidate bytes + prefix", 14: "M classify + write + publish"}
 
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
     k = int(sys.argv[2])
@@ -32,11 +33,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     L.tsqa_debug_stats(enc, None)
     e = list(enc)
     T = max(e[15], 1)
-    print(f"{k} {e[11] / T:.1f} {e[12] / T:.3f} {e[10] / T:.1f}")
+    a, b = (13, 14) if k >= 10 else (11, 12)
+    print(f"{k} {e[a] / T:.1f} {e[b] / T:.3f} {(e[4] if k >= 10 else e[10]) / T:.1f}")
     sys.exit(0)
 
 rows = []
-for k in range(7):
+for k in list(range(7)) + [10, 11, 12, 13, 14]:
     out = subprocess.run([sys.executable, __file__, "--one", str(k)] + sys.argv[1:], capture_output=True, text=True, timeout=300)
     line = [l for l in out.stdout.splitlines() if l and l[0].isdigit()]
     if not line:
@@ -46,4 +48,4 @@ timer = rows[0][1] / max(rows[0][2], 1e-9)
 print(f"timer cost per pass: {timer:.0f} cycles")
 for r in rows[1:]:
     k, cyc, passes, total = int(r[0]), r[1], r[2], r[3]
-    print(f"  {NAMES[k]:22s} {cyc - passes * timer:7.0f} cycles/tile  ({passes:.2f} passes/tile, {(cyc / max(passes, 1e-9)) - timer:6.0f} per pass; parser total in this build {total:.0f})")
+    print(f"  {NAMES[k]:30s} {cyc - passes * timer:7.0f} cycles/tile  ({passes:.2f} passes/tile, {(cyc / max(passes, 1e-9)) - timer:6.0f} per pass; wave total in this build {total:.0f})")

@@ -36,7 +36,8 @@ struct StageCfg {
     static constexpr uint32_t ITEM_WORDS = 80;
     static constexpr uint32_t RING = 128;
     static constexpr uint32_t R = 8;                              // tile records in flight
-    static constexpr uint32_t OWN_MASK = 0xFFFFu;                 // owner image: hash folded to 16 bits
+    static constexpr uint32_t OWN_MASK = 0x7FFFu;                 // owner image: hash folded to 15 bits
+    static constexpr uint32_t WIN = 81920;                        // input window ring: the last 64 KiB of input and then some (a multiple of 64)
     static constexpr uint32_t W16 = 16;                           // word offset of the uint4-per-lane input words
     static constexpr uint32_t ARR = 16 + 256;                     // word offset of the u32-per-lane arrays
     static constexpr uint32_t REC_WORDS = ARR + 12 * 64;
@@ -45,7 +46,8 @@ struct StageCfg {
     static constexpr uint32_t off_ring = off_queue + Q * ITEM_WORDS * 4;       // u32[RING]
     static constexpr uint32_t off_rec = off_ring + RING * 4;                   // u32[R * REC_WORDS]
     static constexpr uint32_t off_ctl = off_rec + R * REC_WORDS * 4;           // u32[64]
-    static constexpr uint32_t total = off_ctl + 256;
+    static constexpr uint32_t off_win = off_ctl + 256;                         // u8[WIN + 32]: the ring, its first 32 bytes mirrored at the end
+    static constexpr uint32_t total = off_win + WIN + 32;
 };
 // ctl words: 0 queue head, 1 queue tail, 2 tiles scanned, 3 tiles matched, 4 tiles with orbits, 5 tiles parsed,
 //            6 stop, 16 + 2*(t&7): visited mask of tile t (lo, hi)
@@ -67,7 +69,12 @@ enum : uint32_t { kAH = 0, kATin = 1, kATp1 = 3, kATp2 = 5, kASpan = 7, kALane =
 #endif
 #define REG_BEGIN(k) unsigned long long r0_##k = 0; if (k == TSQ_REGION) r0_##k = __builtin_amdgcn_s_memtime()
 #define REG_END(k) do { if (k == TSQ_REGION) { st_[11] += __builtin_amdgcn_s_memtime() - r0_##k; st_[12] += 1; } } while (0)
+// the same for the MATCH wave (regions 10..14); the end of a region drains the memory counters so that latency lands in it
+#define MREG_BEGIN(k) unsigned long long m0_##k = 0; if (k == TSQ_REGION) m0_##k = __builtin_amdgcn_s_memtime()
+#define MREG_END(k) do { if (k == TSQ_REGION) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); st_[13] += __builtin_amdgcn_s_memtime() - m0_##k; st_[14] += 1; } } while (0)
 #else
+#define MREG_BEGIN(k) do {} while (0)
+#define MREG_END(k) do {} while (0)
 #define REG_BEGIN(k) do {} while (0)
 #define REG_END(k) do {} while (0)
 #define TSQ_BEGIN() do {} while (0)
@@ -109,6 +116,7 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
     const uint32_t n_tiles = (n >> 6) + 3u;            // visits reach at most n + 63
     uint32_t h_m1 = 0xFFFFFFFFu, h_m2 = 0xFFFFFFFFu, h_m3 = 0xFFFFFFFFu;   // hashes of tiles t-1 .. t-3 (per lane)
     uint32_t id = 1;                                    // (t % 3) + 1: which of the three live tiles an owner tag names
+    uint32_t wbase = 0;                                 // (t * 64) % WIN
 #ifdef TSQ_STATS
     unsigned long long st_[32] = {0};
 #endif
@@ -121,9 +129,9 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
         const uint32_t h = hash4(w16.x);
         const uint32_t hf = h & StageCfg::OWN_MASK;
         const uint32_t tag = (id << 6) | lane;          // never 0: the image starts zeroed
+        const uint32_t before = owner[hf];              // non-zero: a lane of tile t-1, t-2 or t-3 may have this hash
         // retire the entries of tile t-3 (same id as tile t) unless a later tile has taken the bucket over
         if (t >= 3u && ((uint32_t)owner[h_m3 & StageCfg::OWN_MASK] >> 6) == id) owner[h_m3 & StageCfg::OWN_MASK] = 0;
-        const uint32_t before = owner[hf];              // non-zero: a lane of tile t-1 or t-2 may have this hash
         owner[hf] = (uint8_t)tag;
         // twins inside the tile: for each lane the mask of EARLIER lanes with the same hash
         uint64_t twin_in = 0, twins_here = 0;
@@ -137,15 +145,15 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
                 shared &= ~grp;
             }
         }
-        // twins in the two previous tiles
-        uint64_t twin_p1 = 0, twin_p2 = 0;
+        // twins in the three previous tiles (t-1 and t-2 are the parser's business, t-3 is MATCH's)
+        uint64_t twin_p1 = 0, twin_p2 = 0, twin_p3 = 0;
         {
             uint64_t maybe = __ballot(before != 0u);
             while (maybe) {
                 const uint32_t hl = rdlane(h, lsb64(maybe));
-                const uint64_t g1 = __ballot(h_m1 == hl), g2 = __ballot(h_m2 == hl);
+                const uint64_t g1 = __ballot(h_m1 == hl), g2 = __ballot(h_m2 == hl), g3 = __ballot(h_m3 == hl);
                 const uint64_t grp_cur = __ballot(h == hl);
-                if (h == hl) { twin_p1 = g1; twin_p2 = g2; }
+                if (h == hl) { twin_p1 = g1; twin_p2 = g2; twin_p3 = g3; }
                 maybe &= ~grp_cur;
             }
         }
@@ -153,6 +161,11 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
         {
             u32x4_t v; v.x = w16.x; v.y = w16.y; v.z = w16.z; v.w = w16.w;
             *(volatile lds_u32x4_t*)(rec + StageCfg::W16 + lane * 4u) = v;
+            // the tile's 64 input bytes join the window ring MATCH takes candidate bytes from
+            if ((lane & 15u) == 0u) {
+                *(volatile lds_u32x4_t*)(lds + StageCfg::off_win + wbase + lane) = v;
+                if (wbase == 0u && lane < 32u) *(volatile lds_u32x4_t*)(lds + StageCfg::off_win + StageCfg::WIN + lane) = v;
+            }
         }
         if (lane == 0) { rec[0] = (uint32_t)twins_here; rec[1] = (uint32_t)(twins_here >> 32); }
         volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
@@ -160,9 +173,11 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
         arr[kATin * 64] = (uint32_t)twin_in;  arr[(kATin + 1) * 64] = (uint32_t)(twin_in >> 32);
         arr[kATp1 * 64] = (uint32_t)twin_p1;  arr[(kATp1 + 1) * 64] = (uint32_t)(twin_p1 >> 32);
         arr[kATp2 * 64] = (uint32_t)twin_p2;  arr[(kATp2 + 1) * 64] = (uint32_t)(twin_p2 >> 32);
+        arr[kASpan * 64] = (uint32_t)twin_p3; arr[kALane * 64] = (uint32_t)(twin_p3 >> 32);    // MATCH reads these two, then overwrites them
         stage_publish(ctl, 2, t + 1u, lane);
         h_m3 = h_m2; h_m2 = h_m1; h_m1 = h;
         id = id == 3u ? 1u : id + 1u;
+        wbase = wbase + 64u == StageCfg::WIN ? 0u : wbase + 64u;
     }
 #ifdef TSQ_STATS
     if (blockIdx.x == 0 && lane == 0) { g_enc_stats[0] = st_[0]; g_enc_stats[1] = TSQ_TOTAL(); }
@@ -180,8 +195,7 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
     const uint32_t n_tiles = (n >> 6) + 3u;
     uint32_t h_m1 = 0, h_m2 = 0, h_m3 = 0;
     uint64_t tw_m1 = 0, tw_m2 = 0, tw_m3 = 0;          // "has an earlier twin inside its tile" masks of those tiles
-    uint32_t tv_pre = 0;                               // table entries of the NEXT tile, gathered while this tile's candidate bytes fly
-    bool pre = false;
+    uint32_t wbase = 0;                                // (t * 64) % WIN
 #ifdef TSQ_STATS
     unsigned long long st_[32] = {0};
 #endif
@@ -201,6 +215,7 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
     };
     TSQ_BEGIN();
     for (uint32_t t = 0; t < n_tiles; ++t) {
+        MREG_BEGIN(10);
         if (!stage_wait(ctl, 2, t + 1u, 2)) break;
         volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
         volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
@@ -211,29 +226,48 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         const uint64_t twin_p1 = (uint64_t)arr[kATp1 * 64] | ((uint64_t)arr[(kATp1 + 1) * 64] << 32);
         const uint32_t tp2_any = arr[kATp2 * 64] | arr[(kATp2 + 1) * 64];
         const uint64_t twins_here = (uint64_t)uniform(rec[0]) | ((uint64_t)uniform(rec[1]) << 32);
-        // ---- the table must hold exactly the visits of tiles <= t-3 when tile t is gathered
-        uint32_t tv;
-        if (pre) tv = tv_pre;                                   // gathered during the previous iteration
-        else {
-            if (t >= 3u) {
-                if (!stage_wait(ctl, 5, t - 2u, 3)) break;
-                commit(t - 3u, h_m3, tw_m3);
-            }
-            tv = table[h];
+        const uint32_t tp3_lo = arr[kASpan * 64], tp3_hi = arr[kALane * 64];
+        MREG_END(10);
+        MREG_BEGIN(12);
+        // ---- the table holds the visits of tiles <= t-4 (commit(t-4) was issued at the end of the previous iteration):
+        //      gather from it right away, without waiting for the parser ...
+        const uint32_t tv_old = table[h];
+        MREG_END(12);
+        MREG_BEGIN(11);
+        // ... and bring the entries up to "visits of tiles <= t-3" once the parser has finished tile t-3: a lane with a
+        // visited twin there takes the most recent one (what the committed table would hold), the others keep theirs
+        uint32_t tv = tv_old;
+        if (t >= 3u) {
+            if (!stage_wait(ctl, 5, t - 2u, 3)) break;
+            const uint32_t slot = 16u + 2u * ((t - 3u) & 7u);
+            const uint32_t v3_lo = uniform(__hip_atomic_load(&ctl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            const uint32_t v3_hi = uniform(__hip_atomic_load(&ctl[slot + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            const uint32_t hit_lo = tp3_lo & v3_lo, hit_hi = tp3_hi & v3_hi;
+            const uint32_t q = hit_hi ? 63u - (uint32_t)__builtin_clz(hit_hi) : 31u - (uint32_t)__builtin_clz(hit_lo | 1u);
+            if ((hit_lo | hit_hi) != 0u) tv = (((t - 3u) << 6) + q) & 0xFFFFu;
+            commit(t - 3u, h_m3, tw_m3);                    // for the next tile's gather; nothing here waits for these stores
         }
-        // ---- candidates of tile t: their bytes are gathered now ...
+        MREG_END(11);
+        // ---- candidates of tile t
         const uint32_t p = (t << 6) + lane;
         const uint32_t cand0 = candidate_of(tv, p);
-        const uint4 cb = ld128z(src, cand0, avail);
-        // ... and while they fly, the next tile's table entries, if the parser is far enough (it has finished tile t-2)
-        pre = false;
-        if (t + 1u < n_tiles && stage_ready(ctl, 2, t + 2u) && (t < 2u || stage_ready(ctl, 5, t - 1u))) {
-            const uint32_t h_next = (recs + ((t + 1u) % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::ARR + lane)[kAH * 64];
-            if (t >= 2u) commit(t - 2u, h_m2, tw_m2);
-            tv_pre = table[h_next];
-            pre = true;
+        MREG_BEGIN(13);
+        // their 16 bytes come from the window ring in LDS (SCAN has written everything below (t+1)*64); the few lanes whose
+        // candidate ends beyond that (closer than 19 bytes to the tile's end) gather from global memory
+        uint4 cb;
+        {
+            int32_t wi = (int32_t)(wbase + lane) - (int32_t)(p - cand0);
+            wi += wi < 0 ? (int32_t)StageCfg::WIN : 0;
+            volatile lds_u32_t* wp = (volatile lds_u32_t*)(lds + StageCfg::off_win + ((uint32_t)wi & ~3u));
+            const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2], d3 = wp[3], d4 = wp[4];
+            const uint32_t sh = (uint32_t)wi & 3u;
+            cb = make_uint4(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                            __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh));
+            if (cand0 + 19u > ((t + 1u) << 6) || p - cand0 > 65536u) cb = ld128z(src, cand0, avail);
         }
         uint32_t k0 = prefix16(w16, cb);
+        MREG_END(13);
+        MREG_BEGIN(14);
         if (EXT) {
             uint32_t more = 16;
             while (__ballot(k0 == more) != 0ull && more < 64u) {
@@ -264,28 +298,74 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         arr[kASpan * 64] = span_nat | (hard_l ? 0x100u : 0u) | (twin_l ? 0x200u : 0u) | (certain ? 0x400u : 0u) | (neart ? 0x800u : 0u) | (k0 << 16);
         arr[kALane * 64] = cand0 | (nib << 24);
         stage_publish(ctl, 3, t + 1u, lane);
+        MREG_END(14);
         h_m3 = h_m2; h_m2 = h_m1; h_m1 = h;
         tw_m3 = tw_m2; tw_m2 = tw_m1; tw_m1 = twins_here;
+        wbase = wbase + 64u == StageCfg::WIN ? 0u : wbase + 64u;
     }
 #ifdef TSQ_STATS
-    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[2] = st_[2]; g_enc_stats[3] = st_[3]; g_enc_stats[4] = TSQ_TOTAL(); }
+    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[2] = st_[2]; g_enc_stats[3] = st_[3]; g_enc_stats[4] = TSQ_TOTAL(); g_enc_stats[13] = st_[13]; g_enc_stats[14] = st_[14]; }
 #endif
 }
 
 // --------------------------------------------------------------------------------------------- ORBIT
+template <bool EXT>
 __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t lane)
 {
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
+    constexpr uint32_t kDMin = EXT ? 128u : 64u;
+    const uint32_t tail_from = n >= 5u ? n - 5u : 0u;
     const uint32_t n_tiles = (n >> 6) + 3u;
 #ifdef TSQ_STATS
     unsigned long long st_[32] = {0};
 #endif
     TSQ_BEGIN();
     for (uint32_t t = 0; t < n_tiles; ++t) {
+        volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
+        volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
+        // ---- late classification of lanes whose only twins are in tile t-2.  By now the parser has (almost always)
+        //      finished that tile, so which of those twins were visited is known: the most recent visited one IS the
+        //      candidate (tsq_encode.cpp:76-79), 65..191 bytes back.  Such a lane becomes an ordinary certain lane and
+        //      never reaches the parser's scalar path.  (Lanes that also have twins in tile t-1 or t stay hazards.)
+        //      All of this needs only SCAN's part of the record, so it runs while MATCH is still gathering tile t.
+        uint32_t fix_sw = 0, fix_lw = 0;
+        bool fix = false, clear_tp2 = false;
+        if (t >= 2u) {
+            if (!stage_wait(ctl, 2, t + 1u, 6)) break;
+            const uint32_t tp2_lo = arr[kATp2 * 64], tp2_hi = arr[(kATp2 + 1) * 64];
+            const uint32_t nearer = arr[kATin * 64] | arr[(kATin + 1) * 64] | arr[kATp1 * 64] | arr[(kATp1 + 1) * 64];
+            const uint32_t p = (t << 6) + lane;
+            const bool only2 = (tp2_lo | tp2_hi) != 0u && nearer == 0u && p < tail_from;
+            if (__ballot(only2) != 0ull) {
+                if (!stage_wait(ctl, 5, t - 1u, 5)) break;                       // the parser has finished tile t-2
+                const uint32_t slot = 16u + 2u * ((t - 2u) & 7u);
+                const uint32_t v2_lo = uniform(__hip_atomic_load(&ctl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                const uint32_t v2_hi = uniform(__hip_atomic_load(&ctl[slot + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                const uint32_t hit_lo = tp2_lo & v2_lo, hit_hi = tp2_hi & v2_hi;
+                clear_tp2 = only2;                       // visited or not, tile t-2 is settled for this lane
+                if (only2 && (hit_lo | hit_hi) != 0u) {
+                    const uint32_t q = hit_hi ? 63u - (uint32_t)__builtin_clz(hit_hi) : 31u - (uint32_t)__builtin_clz(hit_lo);
+                    const uint32_t cand = (t << 6) - 128u + q;
+                    const u32x4_t a = *(volatile lds_u32x4_t*)(rec + StageCfg::W16 + lane * 4u);
+                    const u32x4_t b = *(volatile lds_u32x4_t*)(recs + ((t - 2u) % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::W16 + q * 4u);
+                    const uint32_t k = prefix16(make_uint4(a.x, a.y, a.z, a.w), make_uint4(b.x, b.y, b.z, b.w));
+                    // exact when the outcome cannot depend on the pair origin (as for the table's candidates) and, with
+                    // extensions, when the first 16 bytes decide the length; otherwise the lane stays a hazard
+                    if (p - cand >= kDMin && !(EXT && k >= 16u)) {
+                        const bool eq4 = k >= 4u;
+                        const uint32_t nib = length_nibble(eq4 ? k : 4u);
+                        fix_sw = (eq4 ? nibble_span(nib) | 0x400u : 1u) | (k << 16);
+                        fix_lw = cand | (nib << 24);
+                        fix = true;
+                    } else clear_tp2 = false;
+                }
+            }
+        }
         if (!stage_wait(ctl, 3, t + 1u, 6)) break;
-        volatile lds_u32_t* arr = recs + (t % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::ARR + lane;
-        const uint32_t sw = arr[kASpan * 64];
+        uint32_t sw = arr[kASpan * 64];
+        if (fix) { sw = fix_sw; arr[kASpan * 64] = fix_sw; arr[kALane * 64] = fix_lw; }
+        if (clear_tp2) { arr[kATp2 * 64] = 0; arr[(kATp2 + 1) * 64] = 0; }
         // the whole orbit of every lane, by pointer doubling: `nx` = where the orbit started at this lane halts
         // (lane, or position past the tile: 7 bits | halted: bit 7), `orb` = the lanes it visits before that.
         // A hop halts when it lands on a hard lane or past the tile.  Twin lanes do not halt: the parser takes
@@ -295,8 +375,8 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
         const uint32_t there = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((c & 63u) << 2), (int)self);
         uint32_t nx = c >= 64u ? (c | 0x80u) : there;
         uint64_t orb = 1ull << lane;
-        for (int round = 0; round < 6; ++round) {
-            if (__ballot((nx & 0x80u) == 0u) == 0ull) break;                    // every orbit has halted
+#pragma unroll
+        for (int round = 0; round < 6; ++round) {                               // (testing "all halted" each round costs more than it saves)
             const int at = (int)((nx & 63u) << 2);
             const uint32_t nx2 = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)nx);
             const uint32_t olo = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)(uint32_t)orb);
@@ -309,7 +389,7 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
         stage_publish(ctl, 4, t + 1u, lane);
     }
 #ifdef TSQ_STATS
-    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[6] = st_[6]; g_enc_stats[7] = TSQ_TOTAL(); }
+    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[6] = st_[6] + st_[5]; g_enc_stats[7] = TSQ_TOTAL(); }
 #endif
 }
 
@@ -696,7 +776,7 @@ __global__ __launch_bounds__(320) void enc_stage_kernel(const uint8_t* __restric
     lds_u8_t* lds3 = (lds_u8_t*)stage_lds;
     if (role == 0) stage_scan(src, avail, n, lds3, lane);
     else if (role == 1) stage_match<EXT>(src, avail, n, table, lds3, lane);
-    else if (role == 2) stage_orbit(n, lds3, lane);
+    else if (role == 2) stage_orbit<EXT>(n, lds3, lane);
     else if (role == 3) stage_parser<EXT>(src, avail, n, lds3, lane);
     else pipe_builder<StageCfg>(src, avail, out, lds3, lane, b, sizes, status);
 }

@@ -15,6 +15,8 @@
 
 namespace tsq {
 
+constexpr uint32_t kEncMaxLds = StageCfg::total > TileCfg::total ? StageCfg::total : TileCfg::total;
+
 inline int launch_encode_fast(tsqa_ctx* c, const uint8_t* in, size_t n, size_t readable, uint32_t ext, int32_t* status, hipStream_t s)
 {
     const uint32_t nb = (uint32_t)((n + kBlockSize - 1) / kBlockSize);
@@ -28,8 +30,8 @@ inline int launch_encode_fast(tsqa_ctx* c, const uint8_t* in, size_t n, size_t r
                               reinterpret_cast<const void*>(enc_orbit_kernel<true>), reinterpret_cast<const void*>(enc_orbit_kernel<false>),
                               reinterpret_cast<const void*>(enc_pipe_kernel<true>), reinterpret_cast<const void*>(enc_pipe_kernel<false>)};
         for (const void* fn : fns)
-            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TileCfg::total) != hipSuccess) {
-                c->set_error("cannot reserve %u B of LDS", TileCfg::total);
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEncMaxLds) != hipSuccess) {
+                c->set_error("cannot reserve %u B of LDS", kEncMaxLds);
                 return TSQA_ERR_HIP;
             }
         attr_set = true;
