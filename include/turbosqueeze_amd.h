@@ -115,9 +115,10 @@ int tsqa_profile_enable(tsqa_ctx *ctx, int on);
 int tsqa_profile_read(tsqa_ctx *ctx, double *encode_ms, uint32_t *encode_launches,
                       double *decode_ms, uint32_t *decode_launches);
 
-/* Kernel variant selection for A/B measurements: 0 = default (fastest validated), 2 = windowed
- * scalar-walk encoder, 3 = single-wave orbit encoder, 4 = two-wave parser/builder encoder (encode only),
- * 1 = serial reference kernels (one lane walks the block; correctness baseline). */
+/* Kernel variant selection for A/B measurements: 0 = default (five-wave staged encoder, ring decoder),
+ * 1 = serial kernels (one lane walks the block; correctness baseline), 2 = windowed scalar-walk encoder /
+ * chunked decoder without history ring, and encode only: 3 = single-wave orbit, 4 = two-wave
+ * parser/builder, 5 = three-wave tile pipeline. */
 void tsqa_set_kernel_variant(tsqa_ctx *ctx, int encode_variant, int decode_variant);
 
 /* =====================================================================================

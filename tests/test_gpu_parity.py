@@ -209,15 +209,16 @@ def test_container_errors(codec, tsq, oracle):
     assert to_bytes(codec.decompress(to_dev(np.frombuffer(good, dtype=np.uint8)))) == bytes(tsq.synth.text(300000, 2))
 
 
-def test_serial_and_fast_kernels_agree(tsq, oracle):
+def test_all_kernel_variants_agree(tsq, oracle):
+    """Every encoder / decoder generation kept for A/B produces the oracle's bytes."""
     c = tsq.DeviceCodec(0)
-    host = tsq.synth.text(9_000_000, seed=21)
+    host = np.concatenate([tsq.synth.text(6_000_000, seed=21), tsq.synth.mix(3_000_000, seed=22)])
     dev = to_dev(host)
-    outs = []
-    for variant in (0, 1):
-        c.set_variant(variant, variant)
-        blob = c.compress(dev, 1)
-        outs.append(to_bytes(blob))
-        assert to_bytes(c.decompress(blob)) == host.tobytes()
-    assert outs[0] == outs[1] == oracle.compress(host, 1, threads=4)
+    for ext in (0, 1):
+        want = oracle.compress(host, ext, threads=4)
+        for enc_variant, dec_variant in ((0, 0), (1, 1), (2, 2), (3, 0), (4, 0), (5, 0)):
+            c.set_variant(enc_variant, dec_variant)
+            blob = c.compress(dev, ext)
+            assert to_bytes(blob) == want, (enc_variant, ext)
+            assert to_bytes(c.decompress(blob)) == host.tobytes(), (dec_variant, ext)
     c.close()

@@ -28,16 +28,18 @@ codec = tsq.DeviceCodec(0)
 blob = codec.compress(src, ext)
 back = codec.decompress(blob)
 assert torch.equal(back, src)
-enc = (C.c_ulonglong * 32)()
+enc = (C.c_ulonglong * 48)()
 dec = (C.c_ulonglong * 16)()
 L.tsqa_debug_stats(enc, dec)
 e = list(enc); d = list(dec)
 T = max(e[15], 1)
 print(f"ENC staged pipeline block0 (tiles parsed={e[15]}, symbols={e[16]}); cycles per tile, busy = total - waited:")
 print("  SCAN    total=%.0f waited(ring)=%.0f busy=%.0f" % (e[1] / T, e[0] / T, (e[1] - e[0]) / T))
+print("          suspect lanes per tile=%.2f (from previous tiles %.2f), group rounds per tile=%.2f" % (e[32] / T, e[34] / T, e[33] / T))
 print("  MATCH   total=%.0f waited(scan)=%.0f waited(parser)=%.0f busy=%.0f" % (e[4] / T, e[2] / T, e[3] / T, (e[4] - e[2] - e[3]) / T))
 print("  ORBIT   total=%.0f waited=%.0f busy=%.0f" % (e[7] / T, e[6] / T, (e[7] - e[6]) / T))
 print("  PARSER  total=%.0f waited(orbit)=%.0f waited(queue)=%.0f busy=%.0f" % (e[10] / T, e[8] / T, e[9] / T, (e[10] - e[8] - e[9]) / T))
+
 print("  BUILDER total=%.0f waited=%.0f busy=%.0f" % (e[18] / T, e[17] / T, (e[18] - e[17]) / T))
 print("  parser events per tile: flagged-checks=%.2f stale-truncations=%.2f segments=%.2f hazard-lanes=%.2f (hard %.2f) replays=%.2f" % tuple(e[k] / T for k in (22, 23, 24, 26, 27, 28)))
 print("  hazard lanes per tile by candidate: twin in tile=%.3f in t-1=%.3f in t-2=%.3f | twin far enough=%.3f | resolved as match=%.3f" % tuple(e[k] / T for k in (29, 30, 31, 20, 21)))

@@ -29,7 +29,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     codec = tsq.DeviceCodec(0)
     blob = codec.compress(src, ext)
     assert torch.equal(codec.decompress(blob), src)
-    enc = (C.c_ulonglong * 32)()
+    enc = (C.c_ulonglong * 48)()
     L.tsqa_debug_stats(enc, None)
     e = list(enc)
     T = max(e[15], 1)

@@ -37,7 +37,8 @@ struct StageCfg {
     static constexpr uint32_t RING = 128;
     static constexpr uint32_t R = 8;                              // tile records in flight
     static constexpr uint32_t OWN_MASK = 0x7FFFu;                 // owner image: hash folded to 15 bits
-    static constexpr uint32_t WIN = 81920;                        // input window ring: the last 64 KiB of input and then some (a multiple of 64)
+    static constexpr uint32_t WIN = 73728;                        // input window ring: the last 64 KiB of input and then some (a multiple of 64)
+    static constexpr uint32_t F_MASK = 0xFFFu;                    // MATCH's filter of tile t-3's visited lanes: hash folded to 12 bits
     static constexpr uint32_t W16 = 16;                           // word offset of the uint4-per-lane input words
     static constexpr uint32_t ARR = 16 + 256;                     // word offset of the u32-per-lane arrays
     static constexpr uint32_t REC_WORDS = ARR + 12 * 64;
@@ -46,7 +47,8 @@ struct StageCfg {
     static constexpr uint32_t off_ring = off_queue + Q * ITEM_WORDS * 4;       // u32[RING]
     static constexpr uint32_t off_rec = off_ring + RING * 4;                   // u32[R * REC_WORDS]
     static constexpr uint32_t off_ctl = off_rec + R * REC_WORDS * 4;           // u32[64]
-    static constexpr uint32_t off_win = off_ctl + 256;                         // u8[WIN + 32]: the ring, its first 32 bytes mirrored at the end
+    static constexpr uint32_t off_f = off_ctl + 256;                           // u8[F_MASK + 1]
+    static constexpr uint32_t off_win = off_f + F_MASK + 1u;                   // u8[WIN + 32]: the ring, its first 32 bytes mirrored at the end
     static constexpr uint32_t total = off_win + WIN + 32;
 };
 // ctl words: 0 queue head, 1 queue tail, 2 tiles scanned, 3 tiles matched, 4 tiles with orbits, 5 tiles parsed,
@@ -121,17 +123,19 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
     unsigned long long st_[32] = {0};
 #endif
     TSQ_BEGIN();
+    uint4 w_next = ld128z(src, lane, avail);
     for (uint32_t t = 0; t < n_tiles; ++t) {
         // the slot of tile t-R is free once the parser has finished tile t-R+2 (it reads the words of two tiles back)
         if (t + 3u > StageCfg::R && !stage_wait(ctl, 5, t + 3u - StageCfg::R, 0)) break;
         const uint32_t p = (t << 6) + lane;
-        const uint4 w16 = ld128z(src, p, avail);
+        const uint4 w16 = w_next;
+        w_next = ld128z(src, (uint64_t)p + 64u, avail);    // the next tile's words: this wave's only global access, a full iteration ahead
         const uint32_t h = hash4(w16.x);
         const uint32_t hf = h & StageCfg::OWN_MASK;
         const uint32_t tag = (id << 6) | lane;          // never 0: the image starts zeroed
-        const uint32_t before = owner[hf];              // non-zero: a lane of tile t-1, t-2 or t-3 may have this hash
         // retire the entries of tile t-3 (same id as tile t) unless a later tile has taken the bucket over
         if (t >= 3u && ((uint32_t)owner[h_m3 & StageCfg::OWN_MASK] >> 6) == id) owner[h_m3 & StageCfg::OWN_MASK] = 0;
+        const uint32_t before = owner[hf];              // non-zero: a lane of tile t-1 or t-2 may have this hash
         owner[hf] = (uint8_t)tag;
         // twins inside the tile: for each lane the mask of EARLIER lanes with the same hash
         uint64_t twin_in = 0, twins_here = 0;
@@ -145,15 +149,17 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
                 shared &= ~grp;
             }
         }
-        // twins in the three previous tiles (t-1 and t-2 are the parser's business, t-3 is MATCH's)
-        uint64_t twin_p1 = 0, twin_p2 = 0, twin_p3 = 0;
+        // twins in the two previous tiles (tile t-3 and older are MATCH's business: by then the parser has decided them)
+        uint64_t twin_p1 = 0, twin_p2 = 0;
         {
             uint64_t maybe = __ballot(before != 0u);
+            TSQ_CNT(20, __builtin_popcountll(maybe));
             while (maybe) {
+                TSQ_CNT(21, 1);
                 const uint32_t hl = rdlane(h, lsb64(maybe));
-                const uint64_t g1 = __ballot(h_m1 == hl), g2 = __ballot(h_m2 == hl), g3 = __ballot(h_m3 == hl);
+                const uint64_t g1 = __ballot(h_m1 == hl), g2 = __ballot(h_m2 == hl);
                 const uint64_t grp_cur = __ballot(h == hl);
-                if (h == hl) { twin_p1 = g1; twin_p2 = g2; twin_p3 = g3; }
+                if (h == hl) { twin_p1 = g1; twin_p2 = g2; }
                 maybe &= ~grp_cur;
             }
         }
@@ -173,14 +179,13 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
         arr[kATin * 64] = (uint32_t)twin_in;  arr[(kATin + 1) * 64] = (uint32_t)(twin_in >> 32);
         arr[kATp1 * 64] = (uint32_t)twin_p1;  arr[(kATp1 + 1) * 64] = (uint32_t)(twin_p1 >> 32);
         arr[kATp2 * 64] = (uint32_t)twin_p2;  arr[(kATp2 + 1) * 64] = (uint32_t)(twin_p2 >> 32);
-        arr[kASpan * 64] = (uint32_t)twin_p3; arr[kALane * 64] = (uint32_t)(twin_p3 >> 32);    // MATCH reads these two, then overwrites them
         stage_publish(ctl, 2, t + 1u, lane);
         h_m3 = h_m2; h_m2 = h_m1; h_m1 = h;
         id = id == 3u ? 1u : id + 1u;
         wbase = wbase + 64u == StageCfg::WIN ? 0u : wbase + 64u;
     }
 #ifdef TSQ_STATS
-    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[0] = st_[0]; g_enc_stats[1] = TSQ_TOTAL(); }
+    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[0] = st_[0]; g_enc_stats[1] = TSQ_TOTAL(); g_enc_stats[32] = st_[20]; g_enc_stats[33] = st_[21]; g_enc_stats[34] = st_[20]; }
 #endif
 }
 
@@ -190,6 +195,7 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
 {
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
+    volatile lds_u8_t* filt = lds + StageCfg::off_f;
     constexpr uint32_t kDMin = EXT ? 128u : 64u;
     const uint32_t tail_from = n >= 5u ? n - 5u : 0u;
     const uint32_t n_tiles = (n >> 6) + 3u;
@@ -199,20 +205,6 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
 #ifdef TSQ_STATS
     unsigned long long st_[32] = {0};
 #endif
-    // commit a tile once the parser has its visited mask: hashes and in-tile twin mask of that tile
-    auto commit = [&](uint32_t tc, uint32_t hc, uint64_t twc) {
-        const uint32_t slot = 16u + 2u * (tc & 7u);
-        const uint64_t vis = (uint64_t)uniform(__hip_atomic_load(&ctl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) |
-                             ((uint64_t)uniform(__hip_atomic_load(&ctl[slot + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) << 32);
-        const uint32_t pc = (tc << 6) + lane;
-        // among equal hashes the highest visited lane must win: lanes with an earlier twin store afterwards, in order
-        if (((vis & ~twc) >> lane) & 1ull) table[hc] = (uint16_t)pc;
-        uint64_t late = vis & twc;
-        while (late) {
-            if (lane == lsb64(late)) table[hc] = (uint16_t)pc;
-            late &= late - 1ull;
-        }
-    };
     TSQ_BEGIN();
     for (uint32_t t = 0; t < n_tiles; ++t) {
         MREG_BEGIN(10);
@@ -226,7 +218,6 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         const uint64_t twin_p1 = (uint64_t)arr[kATp1 * 64] | ((uint64_t)arr[(kATp1 + 1) * 64] << 32);
         const uint32_t tp2_any = arr[kATp2 * 64] | arr[(kATp2 + 1) * 64];
         const uint64_t twins_here = (uint64_t)uniform(rec[0]) | ((uint64_t)uniform(rec[1]) << 32);
-        const uint32_t tp3_lo = arr[kASpan * 64], tp3_hi = arr[kALane * 64];
         MREG_END(10);
         MREG_BEGIN(12);
         // ---- the table holds the visits of tiles <= t-4 (commit(t-4) was issued at the end of the previous iteration):
@@ -235,17 +226,38 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         MREG_END(12);
         MREG_BEGIN(11);
         // ... and bring the entries up to "visits of tiles <= t-3" once the parser has finished tile t-3: a lane with a
-        // visited twin there takes the most recent one (what the committed table would hold), the others keep theirs
+        // visited twin there takes the most recent one (what the committed table would hold), the others keep theirs.
+        // The visited lanes of tile t-3 post themselves in a small filter (hash folded to 12 bits, the highest lane of a
+        // hash last, like the commit); a lane of tile t that finds its own hash there has found its most recent visited
+        // twin; one that finds another hash (a fold collision, rare) is settled with ballots.
         uint32_t tv = tv_old;
         if (t >= 3u) {
             if (!stage_wait(ctl, 5, t - 2u, 3)) break;
             const uint32_t slot = 16u + 2u * ((t - 3u) & 7u);
-            const uint32_t v3_lo = uniform(__hip_atomic_load(&ctl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            const uint32_t v3_hi = uniform(__hip_atomic_load(&ctl[slot + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            const uint32_t hit_lo = tp3_lo & v3_lo, hit_hi = tp3_hi & v3_hi;
-            const uint32_t q = hit_hi ? 63u - (uint32_t)__builtin_clz(hit_hi) : 31u - (uint32_t)__builtin_clz(hit_lo | 1u);
-            if ((hit_lo | hit_hi) != 0u) tv = (((t - 3u) << 6) + q) & 0xFFFFu;
-            commit(t - 3u, h_m3, tw_m3);                    // for the next tile's gather; nothing here waits for these stores
+            const uint64_t vis = (uint64_t)uniform(__hip_atomic_load(&ctl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) |
+                                 ((uint64_t)uniform(__hip_atomic_load(&ctl[slot + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) << 32);
+            const uint32_t p3 = ((t - 3u) << 6) + lane;
+            const bool mine = (vis >> lane) & 1ull;
+            const uint32_t f3 = h_m3 & StageCfg::F_MASK;
+            // among equal hashes the highest visited lane must win: lanes with an earlier twin store afterwards, in order
+            if (((vis & ~tw_m3) >> lane) & 1ull) { table[h_m3] = (uint16_t)p3; filt[f3] = (uint8_t)(0x80u | lane); }
+            uint64_t late = vis & tw_m3;
+            while (late) {
+                if (lane == lsb64(late)) { table[h_m3] = (uint16_t)p3; filt[f3] = (uint8_t)(0x80u | lane); }
+                late &= late - 1ull;
+            }
+            const uint32_t seen = filt[h & StageCfg::F_MASK];
+            const uint32_t q = seen & 63u;
+            const uint32_t hq = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(q << 2), (int)h_m3);
+            if (seen != 0u && hq == h) tv = (((t - 3u) << 6) + q) & 0xFFFFu;
+            uint64_t unsure = __ballot(seen != 0u && hq != h);
+            while (unsure) {                                  // another hash owns the filter slot: this hash's twins, exactly
+                const uint32_t hl = rdlane(h, lsb64(unsure));
+                const uint64_t g3 = __ballot(h_m3 == hl) & vis;
+                if (h == hl && g3 != 0ull) tv = (((t - 3u) << 6) + msb64(g3)) & 0xFFFFu;
+                unsure &= ~__ballot(h == hl);
+            }
+            if (mine) filt[f3] = 0;                           // the filter only ever holds one tile
         }
         MREG_END(11);
         // ---- candidates of tile t
@@ -770,6 +782,8 @@ __global__ __launch_bounds__(320) void enc_stage_kernel(const uint8_t* __restric
         if (threadIdx.x < 64) reinterpret_cast<uint32_t*>(stage_lds + StageCfg::off_ctl)[threadIdx.x] = 0;
         uint4* o4 = reinterpret_cast<uint4*>(stage_lds + StageCfg::off_owner);          // owner image: no valid entries
         for (uint32_t k = threadIdx.x; k < (StageCfg::OWN_MASK + 1u) / 16; k += 320) o4[k] = make_uint4(0, 0, 0, 0);
+        uint4* f4 = reinterpret_cast<uint4*>(stage_lds + StageCfg::off_f);              // MATCH's filter: empty
+        for (uint32_t k = threadIdx.x; k < (StageCfg::F_MASK + 1u) / 16; k += 320) f4[k] = make_uint4(0, 0, 0, 0);
         if (threadIdx.x == 0) { out[0] = (uint8_t)n; out[1] = (uint8_t)(n >> 8); out[2] = (uint8_t)(n >> 16); }
     }
     __syncthreads();

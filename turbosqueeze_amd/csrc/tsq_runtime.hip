@@ -284,9 +284,9 @@ extern "C" int tsqa_decompress_device(tsqa_ctx* c, const void* d_in, size_t n, v
 
 #ifdef TSQ_STATS
 // instrumented builds only: counters published by block 0 of the last encode / decode launch
-extern "C" int tsqa_debug_stats(unsigned long long* enc32, unsigned long long* dec16)
+extern "C" int tsqa_debug_stats(unsigned long long* enc48, unsigned long long* dec16)
 {
-    if (enc32 && hipMemcpyFromSymbol(enc32, HIP_SYMBOL(tsq::g_enc_stats), 32 * sizeof(unsigned long long)) != hipSuccess) return TSQA_ERR_HIP;
+    if (enc48 && hipMemcpyFromSymbol(enc48, HIP_SYMBOL(tsq::g_enc_stats), 48 * sizeof(unsigned long long)) != hipSuccess) return TSQA_ERR_HIP;
     if (dec16 && hipMemcpyFromSymbol(dec16, HIP_SYMBOL(tsq::g_dec_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return TSQA_ERR_HIP;
     return TSQA_OK;
 }
