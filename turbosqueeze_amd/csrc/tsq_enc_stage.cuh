@@ -201,6 +201,7 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
     const uint32_t n_tiles = (n >> 6) + 3u;
     uint32_t h_m1 = 0, h_m2 = 0, h_m3 = 0;
     uint64_t tw_m1 = 0, tw_m2 = 0, tw_m3 = 0;          // "has an earlier twin inside its tile" masks of those tiles
+    uint32_t tin1_lo = 0, tin1_hi = 0, tin2_lo = 0, tin2_hi = 0, tin3_lo = 0, tin3_hi = 0;   // earlier-twin masks of the lanes of those tiles
     uint32_t wbase = 0;                                // (t * 64) % WIN
 #ifdef TSQ_STATS
     unsigned long long st_[32] = {0};
@@ -239,12 +240,15 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
             const uint32_t p3 = ((t - 3u) << 6) + lane;
             const bool mine = (vis >> lane) & 1ull;
             const uint32_t f3 = h_m3 & StageCfg::F_MASK;
-            // among equal hashes the highest visited lane must win: lanes with an earlier twin store afterwards, in order
+            // among equal hashes the highest visited lane must win: lanes with an earlier twin store afterwards ...
             if (((vis & ~tw_m3) >> lane) & 1ull) { table[h_m3] = (uint16_t)p3; filt[f3] = (uint8_t)(0x80u | lane); }
+            // ... one store per hash group: the highest visited lane of a group stores, its earlier twins are dropped unseen
+            // (a block of equal bytes is ONE group of 64 lanes)
             uint64_t late = vis & tw_m3;
             while (late) {
-                if (lane == lsb64(late)) { table[h_m3] = (uint16_t)p3; filt[f3] = (uint8_t)(0x80u | lane); }
-                late &= late - 1ull;
+                const uint32_t top = msb64(late);
+                if (lane == top) { table[h_m3] = (uint16_t)p3; filt[f3] = (uint8_t)(0x80u | lane); }
+                late &= ~((uint64_t)rdlane(tin3_lo, top) | ((uint64_t)rdlane(tin3_hi, top) << 32) | (1ull << top));
             }
             const uint32_t seen = filt[h & StageCfg::F_MASK];
             const uint32_t q = seen & 63u;
@@ -313,6 +317,7 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         MREG_END(14);
         h_m3 = h_m2; h_m2 = h_m1; h_m1 = h;
         tw_m3 = tw_m2; tw_m2 = tw_m1; tw_m1 = twins_here;
+        tin3_lo = tin2_lo; tin3_hi = tin2_hi; tin2_lo = tin1_lo; tin2_hi = tin1_hi; tin1_lo = (uint32_t)twin_in; tin1_hi = (uint32_t)(twin_in >> 32);
         wbase = wbase + 64u == StageCfg::WIN ? 0u : wbase + 64u;
     }
 #ifdef TSQ_STATS
