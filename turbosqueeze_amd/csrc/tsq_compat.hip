@@ -15,7 +15,9 @@
 
 #include "../../include/turbosqueeze.h"
 
+#include <sys/mman.h>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -65,12 +67,44 @@ size_t env_size(const char* name, size_t dflt)
     return v > 0 ? (size_t)v : dflt;
 }
 
+// TSQ_AMD_DEBUG=1: wall-clock marks of the scheduler's steps on stderr
+struct Marks {
+    const bool on = getenv("TSQ_AMD_DEBUG") != nullptr;
+    double t0 = now();
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void at(const char* what) { if (on) { double t = now(); fprintf(stderr, "turbosqueeze_amd: %8.2f ms  %s\n", (t - t0) * 1e3, what); } }
+};
+
 void complain_once(const char* what)
 {
     static std::atomic<bool> said{false};
     if (!said.exchange(true))
         fprintf(stderr, "turbosqueeze_amd: %s -- there is no CPU fallback, the call fails\n", what);
 }
+
+// A fresh malloc() of a gigabyte is a quarter of a million untouched pages; letting the device-to-host copy fault them
+// in one by one costs more than the copy.  A few threads touch them while the kernels run.
+struct Prefault {
+    std::vector<std::thread> th;
+    void start(uint8_t* p, size_t n) {
+        if (!p || n < (size_t(64) << 20)) return;
+        {   // transparent huge pages where the system allows them on request: 2 MiB per fault instead of 4 KiB
+            uintptr_t a0 = (reinterpret_cast<uintptr_t>(p) + 4095) & ~uintptr_t(4095);
+            (void)madvise(reinterpret_cast<void*>(a0), (n - 4096) & ~size_t(4095), MADV_HUGEPAGE);
+        }
+        unsigned hw = std::thread::hardware_concurrency();
+        unsigned k = hw >= 32 ? 16 : hw >= 8 ? 4 : 1;
+        size_t per = ((n / k) + 4095) & ~size_t(4095);
+        for (unsigned i = 0; i < k; ++i) {
+            size_t a = per * i;
+            if (a >= n) break;
+            size_t len = n - a < per ? n - a : per;
+            th.emplace_back([p, a, len] { for (size_t o = 0; o < len; o += 4096) { volatile uint8_t* q = p + a + o; *q = *q; } });   // (keeps what is already there: the header)
+        }
+    }
+    void join() { for (auto& t : th) t.join(); th.clear(); }
+    ~Prefault() { join(); }
+};
 
 // ---- sequential byte source / sink over memory or FILE* ----
 struct Source {
@@ -101,6 +135,8 @@ struct Sink {
     uint8_t* mem = nullptr; size_t cap = 0, at = 0; FILE* f = nullptr; bool own = false; bool failed = false;
     bool open_file(const char* path) { f = fopen(path, "wb"); own = true; return f != nullptr; }
     bool open_mem(size_t capacity) { mem = static_cast<uint8_t*>(malloc(capacity ? capacity : 1)); cap = capacity; return mem != nullptr; }
+    // where the next n bytes will land (memory sinks): the device copies there directly
+    uint8_t* claim(size_t n) { if (f || at + n > cap) { failed = true; return nullptr; } uint8_t* p = mem + at; at += n; return p; }
     void write(const uint8_t* p, size_t n) {
         if (f) { if (fwrite(p, 1, n, f) != n) failed = true; }
         else if (at + n <= cap) memcpy(mem + at, p, n);
@@ -115,7 +151,7 @@ struct Lane {
     tsqa_ctx* dev = nullptr;
     uint8_t *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
     FrameInfo* h_frames = nullptr;
-    size_t in_cap = 0, out_cap = 0, frames_cap = 0;
+    size_t in_cap = 0, out_cap = 0, frames_cap = 0, h_in_cap = 0, h_out_cap = 0;
     uint64_t* h_size = nullptr; int32_t* h_status = nullptr;   // pinned result words
     hipEvent_t ev = nullptr;
 
@@ -125,19 +161,31 @@ struct Lane {
         if (hipHostMalloc(&h_status, sizeof(int32_t), hipHostMallocPortable) != hipSuccess) return false;
         return hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
     }
-    bool reserve(size_t in_bytes, size_t out_bytes, size_t n_frames) {
+    // Device buffers always; pinned host staging only where a FILE* is on that side (memory-to-memory jobs copy
+    // straight between the caller's buffers and HBM: staging would cost a full extra pass over host memory).
+    bool reserve(size_t in_bytes, size_t out_bytes, size_t n_frames, bool stage_in, bool stage_out) {
         (void)hipSetDevice(dev->device);
         if (in_bytes > in_cap) {
-            (void)hipHostFree(h_in); (void)hipFree(d_in); h_in = d_in = nullptr; in_cap = 0;
-            if (hipHostMalloc(&h_in, in_bytes, hipHostMallocPortable) != hipSuccess) return false;
+            (void)hipFree(d_in); d_in = nullptr; in_cap = 0;
+            (void)hipHostFree(h_in); h_in = nullptr; h_in_cap = 0;
             if (hipMalloc(&d_in, in_bytes) != hipSuccess) return false;
             in_cap = in_bytes;
         }
+        if (stage_in && h_in_cap < in_cap) {
+            (void)hipHostFree(h_in); h_in = nullptr; h_in_cap = 0;
+            if (hipHostMalloc(&h_in, in_cap, hipHostMallocPortable) != hipSuccess) return false;
+            h_in_cap = in_cap;
+        }
         if (out_bytes > out_cap) {
-            (void)hipHostFree(h_out); (void)hipFree(d_out); h_out = d_out = nullptr; out_cap = 0;
-            if (hipHostMalloc(&h_out, out_bytes, hipHostMallocPortable) != hipSuccess) return false;
+            (void)hipFree(d_out); d_out = nullptr; out_cap = 0;
+            (void)hipHostFree(h_out); h_out = nullptr; h_out_cap = 0;
             if (hipMalloc(&d_out, out_bytes) != hipSuccess) return false;
             out_cap = out_bytes;
+        }
+        if (stage_out && h_out_cap < out_cap) {
+            (void)hipHostFree(h_out); h_out = nullptr; h_out_cap = 0;
+            if (hipHostMalloc(&h_out, out_cap, hipHostMallocPortable) != hipSuccess) return false;
+            h_out_cap = out_cap;
         }
         if (n_frames > frames_cap) {
             (void)hipHostFree(h_frames); h_frames = nullptr; frames_cap = 0;
@@ -181,7 +229,9 @@ public:
             if (!l.init(devs[k % devs.size()])) { l.destroy(); for (auto& x : lanes_) x.destroy(); lanes_.clear(); return false; }
             lanes_.push_back(l);
         }
-        batch_blocks_ = (uint32_t)env_size("TSQ_AMD_BATCH_BLOCKS", 16);
+        // one batch should fill the device: a block is one workgroup on one CU for its whole (serial) parse
+        batch_blocks_ = (uint32_t)env_size("TSQ_AMD_BATCH_BLOCKS", 256);
+        file_batch_blocks_ = (uint32_t)env_size("TSQ_AMD_FILE_BATCH_BLOCKS", batch_blocks_ < 64 ? batch_blocks_ : 64);
         thread_ = std::thread([this] { loop(); });
         return true;
     }
@@ -249,24 +299,39 @@ private:
         bool ok = true;
         std::deque<InFlight> fly;
         uint32_t done_blocks = 0;
+        const bool stage_in = src.mem == nullptr, stage_out = j.outfile;
+        const uint32_t batch = (stage_in || stage_out) ? file_batch_blocks_ : batch_blocks_;
+        Marks mk; mk.at("compress: buffers opened");
+        Prefault touch;
+        if (!stage_out) touch.start(sink.mem, sink.cap < total ? sink.cap : total);   // (the bound is 1.25x; text lands at 0.6x)
         auto drain_one = [&]() {
             InFlight f = fly.front(); fly.pop_front();
             Lane& l = lanes_[f.lane];
             (void)hipSetDevice(l.dev->device);
             if (hipEventSynchronize(l.ev) != hipSuccess || *l.h_status != 0) { ok = false; return; }
             size_t sz = (size_t)*l.h_size;                            // batch container: 16-byte header + frames
+            mk.at("compress: kernels done");
             if (sz < 16 || sz > l.out_cap) { ok = false; return; }
-            if (hipMemcpyAsync(l.h_out, l.d_out + 16, sz - 16, hipMemcpyDeviceToHost, l.dev->stream) != hipSuccess ||
-                hipStreamSynchronize(l.dev->stream) != hipSuccess) { ok = false; return; }
-            sink.write(l.h_out, sz - 16);
+            if (stage_out) {
+                if (hipMemcpyAsync(l.h_out, l.d_out + 16, sz - 16, hipMemcpyDeviceToHost, l.dev->stream) != hipSuccess ||
+                    hipStreamSynchronize(l.dev->stream) != hipSuccess) { ok = false; return; }
+                sink.write(l.h_out, sz - 16);
+            } else {
+                touch.join();
+                mk.at("compress: output pages touched");
+                uint8_t* dst = sink.claim(sz - 16);                   // frames land in the caller's buffer directly
+                if (!dst || hipMemcpyAsync(dst, l.d_out + 16, sz - 16, hipMemcpyDeviceToHost, l.dev->stream) != hipSuccess ||
+                    hipStreamSynchronize(l.dev->stream) != hipSuccess) { ok = false; return; }
+            }
+            mk.at("compress: D2H done");
             for (uint32_t b = 0; b < f.n_blocks; ++b) {               // tsq_threads.cpp:248-254
                 done_blocks++;
                 if (j.progress) j.progress(j.id, (double)done_blocks / (double)nb);
             }
         };
 
-        for (uint32_t b0 = 0, k = 0; b0 < nb && ok; b0 += batch_blocks_, ++k) {
-            const uint32_t bn = nb - b0 < batch_blocks_ ? nb - b0 : batch_blocks_;
+        for (uint32_t b0 = 0, k = 0; b0 < nb && ok; b0 += batch, ++k) {
+            const uint32_t bn = nb - b0 < batch ? nb - b0 : batch;
             const size_t lane_i = k % lanes_.size();
             while (ok && fly.size() >= lanes_.size()) drain_one();
             if (!ok) break;
@@ -274,13 +339,17 @@ private:
             const size_t at = (size_t)b0 * kBlockSize;
             const size_t want = (size_t)bn * kBlockSize;
             const size_t n = total - at < want ? total - at : want;
-            if (!l.reserve(want + kHalo, tsqa_container_bound(want), 0)) { ok = false; break; }
-            // the batch plus the first bytes of the next one: block k's look-ahead reads block k+1
-            size_t got = src.read_at(at, n + kHalo, l.h_in);
-            if (got < n) { ok = false; break; }
+            if (!l.reserve(want + kHalo, tsqa_container_bound(want), 0, stage_in, stage_out)) { ok = false; break; }
             (void)hipSetDevice(l.dev->device);
             hipStream_t s = l.dev->stream;
-            if (hipMemcpyAsync(l.d_in, l.h_in, got, hipMemcpyHostToDevice, s) != hipSuccess) { ok = false; break; }
+            // the batch plus the first bytes of the next one: block k's look-ahead reads block k+1
+            size_t got = total - at < n + kHalo ? total - at : n + kHalo;
+            if (stage_in) {
+                got = src.read_at(at, n + kHalo, l.h_in);
+                if (got < n) { ok = false; break; }
+                if (hipMemcpyAsync(l.d_in, l.h_in, got, hipMemcpyHostToDevice, s) != hipSuccess) { ok = false; break; }
+            } else if (hipMemcpyAsync(l.d_in, src.mem + at, got, hipMemcpyHostToDevice, s) != hipSuccess) { ok = false; break; }
+            mk.at("compress: H2D issued");
             if (hipMemsetAsync(l.dev->d_status, 0, sizeof(int32_t), s) != hipSuccess) { ok = false; break; }
             if (l.dev->launch_encode(l.d_in, n, got, j.ext ? 1u : 0u, l.dev->d_status, s) != TSQA_OK) { ok = false; break; }
             if (l.dev->launch_pack(n, j.ext ? 1u : 0u, l.d_out, l.out_cap, l.dev->d_size, l.dev->d_status, s) != TSQA_OK) { ok = false; break; }
@@ -316,12 +385,16 @@ private:
         bool ok = true;
         std::deque<InFlight> fly;
         uint32_t done_blocks = 0;
+        const bool stage_in = src.mem == nullptr, stage_out = j.outfile;
+        const uint32_t batch = (stage_in || stage_out) ? file_batch_blocks_ : batch_blocks_;
+        Prefault touch;
+        if (!stage_out) touch.start(sink.mem, (size_t)total);
         auto drain_one = [&]() {
             InFlight f = fly.front(); fly.pop_front();
             Lane& l = lanes_[f.lane];
             (void)hipSetDevice(l.dev->device);
             if (hipEventSynchronize(l.ev) != hipSuccess || *l.h_status != 0) { ok = false; return; }
-            sink.write(l.h_out, f.out_bytes);
+            if (stage_out) sink.write(l.h_out, f.out_bytes);          // (memory sinks: the copy landed in place)
             for (uint32_t b = 0; b < f.n_blocks; ++b) {                // tsq_threads.cpp:654-655
                 done_blocks++;
                 if (j.progress) j.progress(j.id, (double)done_blocks / (double)nb);
@@ -330,25 +403,28 @@ private:
 
         size_t at = 16;                       // container cursor: the frame walk is serial (tsq_threads.cpp:513-524)
         uint64_t produced = 0;
-        const size_t in_budget = (size_t)batch_blocks_ * (3 + kSlotSize);
+        const size_t in_budget = (size_t)batch * (3 + kSlotSize);
         for (uint32_t b0 = 0, k = 0; b0 < nb && ok; ++k) {
             const size_t lane_i = k % lanes_.size();
             while (ok && fly.size() >= lanes_.size()) drain_one();
             if (!ok) break;
             Lane& l = lanes_[lane_i];
-            if (!l.reserve(in_budget + 16, (size_t)batch_blocks_ * kBlockSize + 256, batch_blocks_)) { ok = false; break; }
-            // gather whole frames into the staging buffer until the batch is full
+            if (!l.reserve(in_budget + 16, (size_t)batch * kBlockSize + 256, batch, stage_in, stage_out)) { ok = false; break; }
+            // walk whole frames until the batch is full; the frames of a batch are one contiguous slice of the container
             size_t cur = 0; uint32_t bn = 0; size_t out_bytes = 0;
-            while (b0 + bn < nb && bn < batch_blocks_) {
-                uint8_t fh[3];
-                if (src.read_at(at + cur, 3, fh) != 3) break;
+            while (b0 + bn < nb && bn < batch) {
+                uint8_t fh[6];
+                if (src.read_at(at + cur, 6, fh) != 6) break;
                 uint32_t frame = (uint32_t)fh[0] | ((uint32_t)fh[1] << 8) | ((uint32_t)fh[2] << 16);
                 uint32_t len = frame & 0x7FFFFFu;                                             // tsq_threads.cpp:513-517
                 if (len < 3 || len > kSlotSize) { ok = false; break; }                         // tsq_threads.cpp:526-531
                 if (cur + 3 + len > l.in_cap) break;
-                memcpy(l.h_in + cur, fh, 3);
-                if (src.read_at(at + cur + 3, len, l.h_in + cur + 3) != len) { ok = false; break; }
-                uint32_t usize = (uint32_t)l.h_in[cur + 3] | ((uint32_t)l.h_in[cur + 4] << 8) | ((uint32_t)l.h_in[cur + 5] << 16);
+                if (at + cur + 3 + len > src.size) { ok = false; break; }
+                if (stage_in) {
+                    memcpy(l.h_in + cur, fh, 3);
+                    if (src.read_at(at + cur + 3, len, l.h_in + cur + 3) != len) { ok = false; break; }
+                }
+                uint32_t usize = (uint32_t)fh[3] | ((uint32_t)fh[4] << 8) | ((uint32_t)fh[5] << 16);
                 if (usize > kBlockSize || produced + out_bytes + usize > total) { ok = false; break; }
                 FrameInfo& fi = l.h_frames[bn];
                 fi.stream_at = cur + 3; fi.out_at = out_bytes; fi.stream_len = len; fi.ext = frame >> 23; fi.out_len = usize; fi.pad = 0;
@@ -359,11 +435,16 @@ private:
             (void)hipSetDevice(l.dev->device);
             hipStream_t s = l.dev->stream;
             if (l.dev->reserve(bn, false) != TSQA_OK) { ok = false; break; }
-            if (hipMemcpyAsync(l.d_in, l.h_in, cur, hipMemcpyHostToDevice, s) != hipSuccess) { ok = false; break; }
+            if (hipMemcpyAsync(l.d_in, stage_in ? l.h_in : src.mem + at, cur, hipMemcpyHostToDevice, s) != hipSuccess) { ok = false; break; }
             if (hipMemcpyAsync(l.dev->frames, l.h_frames, bn * sizeof(FrameInfo), hipMemcpyHostToDevice, s) != hipSuccess) { ok = false; break; }
             if (hipMemsetAsync(l.dev->d_status, 0, sizeof(int32_t), s) != hipSuccess) { ok = false; break; }
             if (l.dev->launch_decode(l.d_in, bn, l.d_out, l.dev->d_status, s) != TSQA_OK) { ok = false; break; }
-            (void)hipMemcpyAsync(l.h_out, l.d_out, out_bytes, hipMemcpyDeviceToHost, s);
+            if (stage_out) (void)hipMemcpyAsync(l.h_out, l.d_out, out_bytes, hipMemcpyDeviceToHost, s);
+            else {
+                touch.join();
+                uint8_t* dst = sink.claim(out_bytes);                  // blocks land in the caller's buffer directly
+                if (!dst || hipMemcpyAsync(dst, l.d_out, out_bytes, hipMemcpyDeviceToHost, s) != hipSuccess) { ok = false; break; }
+            }
             (void)hipMemcpyAsync(l.h_status, l.dev->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s);
             if (hipEventRecord(l.ev, s) != hipSuccess) { ok = false; break; }
             fly.push_back({lane_i, b0, bn, out_bytes});
@@ -382,7 +463,7 @@ private:
 
     const bool compress_, verbose_;
     std::vector<Lane> lanes_;
-    uint32_t batch_blocks_ = 16;
+    uint32_t batch_blocks_ = 256, file_batch_blocks_ = 64;
     std::thread thread_;
     std::mutex m_;
     std::condition_variable cv_, idle_cv_;
@@ -439,7 +520,7 @@ struct BlockCodec {
     bool ensure() {
         if (tried) return ready;
         tried = true;
-        ready = lane.init(device_list()[0]) && lane.reserve(kBlockSize + kHalo + kSlotSize, kSlotSize + 256, 1);
+        ready = lane.init(device_list()[0]) && lane.reserve(kBlockSize + kHalo + kSlotSize, kSlotSize + 256, 1, true, true);
         if (!ready) { complain_once("no usable gfx950 device (or HIP initialisation failed)"); }
         return ready;
     }
