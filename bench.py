@@ -194,7 +194,7 @@ def main():
         dom = ("encode", enc_gbs, enc_avg) if enc_avg >= dec_avg else ("decode", dec_gbs, dec_avg)
         traffic, traffic_src = (None, None)
         if args.variant == 0 and args.ext == 0 and n == 1_000_000_000:
-            traffic, traffic_src = pmc_traffic("enc_" if dom[0] == "encode" else "dec_fast")
+            traffic, traffic_src = pmc_traffic("enc_" if dom[0] == "encode" else "dec_")
         line = {
             "metric": "encode+decode GB/s on enwik9-shaped input (round trip of uncompressed bytes)",
             "value": round(value, 4), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -209,6 +209,34 @@ def test_container_errors(codec, tsq, oracle):
     assert to_bytes(codec.decompress(to_dev(np.frombuffer(good, dtype=np.uint8)))) == bytes(tsq.synth.text(300000, 2))
 
 
+def test_corrupted_containers_agree_with_oracle(codec, tsq, oracle):
+    """Hardened decode: random byte damage inside the frames.  The device decoder must come back
+    (every loop of the kernel is bounded) and must agree with the oracle's validating decoder: reject what it
+    rejects, and produce the same bytes where the damaged stream is still well formed."""
+    rng = np.random.default_rng(4242)
+    n_cases = int(os.environ.get("TSQ_GPU_CORRUPT_CASES", "150"))
+    agree_ok = agree_bad = 0
+    for case in range(n_cases):
+        n = int(rng.integers(20_000, 400_000))
+        ext = int(rng.integers(0, 2))
+        good = np.frombuffer(oracle.compress(fuzzgen.structured(rng, n), ext), dtype=np.uint8).copy()
+        for _ in range(int(rng.integers(1, 6))):
+            at = int(rng.integers(16, good.size))
+            good[at] = rng.integers(0, 256) if rng.random() < 0.7 else good[at] ^ (1 << int(rng.integers(0, 8)))
+        want = oracle.decompress(good)
+        try:
+            got = to_bytes(codec.decompress(to_dev(good), out_cap=n + 4096))
+        except tsq.TsqError:
+            got = None
+        if want is None:
+            assert got is None, f"case {case}: the oracle rejects this stream, the device decoded {len(got)} bytes"
+            agree_bad += 1
+        else:
+            assert got == want, f"case {case}: both decoders accept the damaged stream but disagree"
+            agree_ok += 1
+    assert agree_ok + agree_bad == n_cases
+
+
 def test_all_kernel_variants_agree(tsq, oracle):
     """Every encoder / decoder generation kept for A/B produces the oracle's bytes."""
     c = tsq.DeviceCodec(0)
