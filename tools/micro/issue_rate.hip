@@ -10,7 +10,7 @@
 
 __global__ void k_bench(unsigned long long* out, int iters, int which)
 {
-    __shared__ uint32_t lds[256];
+    __shared__ uint32_t lds[512];
     lds[threadIdx.x] = threadIdx.x;
     __syncthreads();
     unsigned long long t0, t1;
@@ -88,20 +88,60 @@ __global__ void k_bench(unsigned long long* out, int iters, int which)
     for (int i = 0; i < iters; ++i) { asm volatile(REP16("v_cmp_ne_u32 %1, 0, %0\n\ts_and_b64 %1, %1, exec\n\tv_cmp_ne_u32 %1, 1, %0\n\ts_and_b64 %1, %1, exec\n\t") : "+v"(v), "+s"(m) :: "scc"); }
     t1 = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) out[11] = t1 - t0;
     }
-    if (threadIdx.x == 0) out[15] = s + a + b + c + d + v + w + idx + (uint32_t)q + (uint32_t)m;
+    // 12: SALU -> VALU (sgpr operand) -> SALU round trip: s_add ; v_and v,s ; v_readfirstlane ; (x32)
+    if (which == 12) {
+    t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) { asm volatile(REP16("s_add_u32 %1, %1, 1\n\tv_and_b32 %0, %1, %0\n\tv_readfirstlane_b32 %2, %0\n\ts_add_u32 %1, %1, %2\n\ts_add_u32 %1, %1, 1\n\tv_and_b32 %0, %1, %0\n\tv_readfirstlane_b32 %2, %0\n\ts_add_u32 %1, %1, %2\n\t") : "+v"(v), "+s"(s), "+s"(a) :: "scc"); }
+    t1 = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) out[12] = t1 - t0;
+    }
+    // 13: SALU writes sgpr, VALU reads it (no way back): s_add ; v_add v, s, v  (x64 pairs... 32 pairs)
+    if (which == 13) {
+    t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) { asm volatile(REP16("s_add_u32 %1, %1, 1\n\tv_add_u32 %0, %1, %0\n\ts_add_u32 %1, %1, 1\n\tv_add_u32 %0, %1, %0\n\t") : "+v"(v), "+s"(s) :: "scc"); }
+    t1 = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) out[13] = t1 - t0;
+    }
+    // 14: 8 v_writelane (sgpr source) + ds_write, x8
+    if (which == 14) {
+    t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) { asm volatile(REP4("v_writelane_b32 %0, %1, 1\n\tv_writelane_b32 %0, %1, 2\n\tv_writelane_b32 %0, %1, 3\n\tv_writelane_b32 %0, %1, 4\n\tv_writelane_b32 %0, %1, 5\n\tv_writelane_b32 %0, %1, 6\n\tv_writelane_b32 %0, %1, 7\n\tv_writelane_b32 %0, %1, 8\n\tds_write_b32 %2, %0\n\t") : "+v"(v) : "s"(s), "v"((uint32_t)(threadIdx.x * 4)) : "memory"); }
+    t1 = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) out[14] = t1 - t0;
+    }
+    // 15: dependent 64-bit bit-scan chain: s_ff1_i32_b64 ; s_lshl_b64 ; s_bcnt1 ; s_flbit
+    if (which == 15) {
+    t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) { asm volatile(REP16("s_ff1_i32_b64 %1, %0\n\ts_lshl_b64 %0, %0, %1\n\ts_bcnt1_i32_b64 %1, %0\n\ts_flbit_i32_b64 %1, %0\n\t") : "+s"(q), "+s"(a) :: "scc"); }
+    t1 = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) out[15] = t1 - t0;
+    }
+    // 16: v_readlane with an SGPR lane select, then use (x32 pairs)
+    if (which == 16) {
+    t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) { asm volatile(REP16("s_and_b32 %2, %2, 63\n\tv_readlane_b32 %1, %0, %2\n\ts_add_u32 %2, %2, %1\n\ts_and_b32 %2, %2, 63\n\tv_readlane_b32 %1, %0, %2\n\ts_add_u32 %2, %2, %1\n\t") : "+v"(v), "+s"(a), "+s"(s) :: "scc"); }
+    t1 = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) out[16] = t1 - t0;
+    }
+    // 17: 11 independent LDS loads + one wait (x4)
+    if (which == 17) {
+    uint32_t r0 = 0;
+    t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) { asm volatile(REP4("ds_read_b32 %0, %1\n\tds_read_b32 %0, %1 offset:256\n\tds_read_b32 %0, %1 offset:512\n\tds_read_b32 %0, %1 offset:768\n\tds_read_b32 %0, %1\n\tds_read_b32 %0, %1 offset:256\n\tds_read_b32 %0, %1 offset:512\n\tds_read_b32 %0, %1 offset:768\n\tds_read_b32 %0, %1\n\tds_read_b32 %0, %1 offset:256\n\tds_read_b32 %0, %1 offset:512\n\ts_waitcnt lgkmcnt(0)\n\t") : "=&v"(r0) : "v"((uint32_t)(threadIdx.x * 4)) : "memory"); }
+    t1 = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) out[17] = t1 - t0;
+    w += r0;
+    }
+    if (threadIdx.x == 0) out[23] = s + a + b + c + d + v + w + idx + (uint32_t)q + (uint32_t)m;
 }
 
 int main()
 {
-    unsigned long long* d; unsigned long long h[16];
+    unsigned long long* d; unsigned long long h[24];
     hipMalloc(&d, sizeof(h));
     hipMemset(d, 0, sizeof(h));
     const int iters = 2000;
-    const char* names[12] = {"dependent s_add (per instr)", "independent s_add x4 (per instr)", "dependent v_add (per instr)", "alternating v_add/s_add (per instr)",
+    const char* names[18] = {"dependent s_add (per instr)", "independent s_add x4 (per instr)", "dependent v_add (per instr)", "alternating v_add/s_add (per instr)",
                              "v_readlane + dependent s_add (per pair)", "taken short branch (cmp+branch)", "not-taken branch (cmp+branch+nop)", "s_memtime (each)",
-                             "dependent LDS load (each)", "taken far branch (cmp+branch over 64 instrs)", "dependent s_lshl_b64 (per instr)", "v_cmp -> s_and_b64 (per pair)"};
-    const double per[12] = {64, 64, 64, 64, 32, 64, 64, 16, 64, 16, 64, 32};
-    for (int k = 0; k < 12; ++k) {
+                             "dependent LDS load (each)", "taken far branch (cmp+branch over 64 instrs)", "dependent s_lshl_b64 (per instr)", "v_cmp -> s_and_b64 (per pair)",
+                             "s_add > v_and(sgpr) > v_readfirstlane > s_add (per round trip)", "s_add > v_add(sgpr) (per pair)", "8 v_writelane + ds_write (per group of 9)",
+                             "ff1/lshl/bcnt/flbit b64 chain (per instr)", "v_readlane with SGPR lane + use (per pair)", "11 LDS loads + wait (per group)"};
+    const double per[18] = {64, 64, 64, 64, 32, 64, 64, 16, 64, 16, 64, 32, 32, 32, 4, 64, 32, 4};
+    for (int k = 0; k < 18; ++k) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipLaunchKernelGGL(k_bench, dim3(1), dim3(64), 0, 0, d, iters, k);
         hipEventRecord(e0);

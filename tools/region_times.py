@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAMES = {0: "(empty: timer cost)", 1: "P wait+loads+prologue", 2: "P orbit+check", 3: "P account", 4: "P resolve", 5: "P flush", 6: "P publish",
+NAMES = {0: "(empty: timer cost)", 1: "P wait+loads+prologue", 2: "P orbit+check", 3: "P account", 4: "P resolve", 5: "P flush", 6: "P publish", 7: "P whole segment loop (non-plain tiles)", 8: "P resolve: candidate (twins, LDS words)", 9: "P resolve: decision + outcome", 15: "P plain-tile attempt (both outcomes)", 16: "P whole tile (incl. waiting)",
          10: "M wait scan + record loads", 11: "M wait parser + commit", 12: "M table gather", 13: "M candidate bytes + prefix", 14: "M classify + write + publish"}
 
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
@@ -33,12 +33,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     L.tsqa_debug_stats(enc, None)
     e = list(enc)
     T = max(e[15], 1)
-    a, b = (13, 14) if k >= 10 else (11, 12)
-    print(f"{k} {e[a] / T:.1f} {e[b] / T:.3f} {(e[4] if k >= 10 else e[10]) / T:.1f}")
+    a, b = (13, 14) if 10 <= k <= 14 else (11, 12)
+    print(f"{k} {e[a] / T:.1f} {e[b] / T:.3f} {(e[4] if 10 <= k <= 14 else e[10]) / T:.1f}")
     sys.exit(0)
 
 rows = []
-for k in list(range(7)) + [10, 11, 12, 13, 14]:
+for k in [int(x) for x in os.environ.get('TSQ_REGIONS', '0 1 2 3 4 5 6 7 8 9 10 11 12 13 14').split()]:
     out = subprocess.run([sys.executable, __file__, "--one", str(k)] + sys.argv[1:], capture_output=True, text=True, timeout=300)
     line = [l for l in out.stdout.splitlines() if l and l[0].isdigit()]
     if not line:
