@@ -41,7 +41,7 @@ print("  ORBIT   total=%.0f waited=%.0f busy=%.0f" % (e[7] / T, e[6] / T, (e[7] 
 print("  PARSER  total=%.0f waited(orbit)=%.0f waited(queue)=%.0f busy=%.0f" % (e[10] / T, e[8] / T, e[9] / T, (e[10] - e[8] - e[9]) / T))
 
 print("  BUILDER total=%.0f waited=%.0f busy=%.0f" % (e[18] / T, e[17] / T, (e[18] - e[17]) / T))
-print("  parser events per tile: plain tiles=%.2f stale-truncations=%.2f segments=%.2f hazard-lanes=%.2f (hard %.2f) replays=%.2f" % tuple(e[k] / T for k in (25, 23, 24, 26, 27, 28)))
+print("  parser events per tile: stale-truncations=%.2f segments=%.2f hazard-lanes=%.2f (hard %.2f) replays=%.2f" % tuple(e[k] / T for k in (23, 24, 26, 27, 28)))
 print("  hazard lanes per tile by candidate: twin in tile=%.3f in t-1=%.3f in t-2=%.3f | twin far enough=%.3f | resolved as match=%.3f" % tuple(e[k] / T for k in (29, 30, 31, 20, 21)))
 print(f"  P6b detail (wave 0): init scan={d[9]} barrier waits={d[10]} read phases={d[11]} write phases={d[15]}")
 names = ["P0 stage", "P1 spec", "P2 dbl", "P3 chain", "P4 expand+scan", "P5 syms", "P6a scatter", "P6b jump", "P7 flush"]
