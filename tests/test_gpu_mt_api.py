@@ -67,9 +67,13 @@ def test_bad_arguments(tsq):                              # tsq_threads.cpp:415-
     assert tsq.tsq_decompress_mt(b"TSQ1" + bytes(12) + bytes(40)) is None   # n_blocks == 0
 
 
-def test_file_modes(tsq, oracle, tmp_path):               # sample/main.cpp:144,160 use file mode
+@pytest.mark.parametrize("inmem_max", ["", "1"])           # whole file in memory / streamed through pinned staging
+def test_file_modes(tsq, oracle, tmp_path, inmem_max, monkeypatch):   # sample/main.cpp:144,160 use file mode
+    if inmem_max:
+        monkeypatch.setenv("TSQ_AMD_FILE_INMEM_MAX", inmem_max)
+        monkeypatch.setenv("TSQ_AMD_FILE_BATCH_BLOCKS", "1")
     L = tsq.lib()
-    host = tsq.synth.text((1 << 22) + 99999, seed=41)
+    host = tsq.synth.text(3 * (1 << 22) + 99999, seed=41)
     src = tmp_path / "in.bin"; mid = tmp_path / "out.tsq"; dst = tmp_path / "back.bin"
     src.write_bytes(host.tobytes())
     c = L.tsqAllocateContextCompression_MT(False)

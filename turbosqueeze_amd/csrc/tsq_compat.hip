@@ -16,6 +16,7 @@
 #include "../../include/turbosqueeze.h"
 
 #include <sys/mman.h>
+#include <unistd.h>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -108,7 +109,7 @@ struct Prefault {
 
 // ---- sequential byte source / sink over memory or FILE* ----
 struct Source {
-    const uint8_t* mem = nullptr; size_t size = 0; FILE* f = nullptr; bool own = false;
+    const uint8_t* mem = nullptr; size_t size = 0; FILE* f = nullptr; bool own = false; uint8_t* loaded = nullptr;
     bool open(const uint8_t* in, size_t szin, bool infile) {
         if (infile) {
             f = fopen(reinterpret_cast<const char*>(in), "rb");          // tsq_threads.cpp:294-310
@@ -117,6 +118,34 @@ struct Source {
             fseek(f, 0, SEEK_END); long s = ftell(f); fseek(f, 0, SEEK_SET);
             if (s < 0) return false;
             size = (size_t)s;
+            // Files that fit in memory are read whole, by several threads, and then go down the memory path (device-filling
+            // batches, direct copies); larger ones stream through pinned staging in smaller batches.
+            if (size > 0 && size <= env_size("TSQ_AMD_FILE_INMEM_MAX", size_t(16) << 30)) {
+                loaded = static_cast<uint8_t*>(malloc(size + kHalo));
+                if (loaded) {
+                    const int fd = fileno(f);
+                    unsigned hw = std::thread::hardware_concurrency();
+                    const unsigned k = size < (size_t(64) << 20) ? 1 : hw >= 32 ? 16 : hw >= 8 ? 4 : 1;
+                    const size_t per = ((size / k) + 4095) & ~size_t(4095);
+                    std::atomic<bool> good{true};
+                    std::vector<std::thread> th;
+                    for (unsigned i = 0; i < k; ++i) {
+                        const size_t a = per * i;
+                        if (a >= size) break;
+                        const size_t len = size - a < per ? size - a : per;
+                        th.emplace_back([this, fd, a, len, &good] {
+                            size_t done = 0;
+                            while (done < len) {
+                                ssize_t r = pread(fd, loaded + a + done, len - done, (off_t)(a + done));
+                                if (r <= 0) { good = false; return; }
+                                done += (size_t)r;
+                            }
+                        });
+                    }
+                    for (auto& t : th) t.join();
+                    if (good) mem = loaded; else { free(loaded); loaded = nullptr; }
+                }
+            }
         } else { mem = in; size = szin; }
         return true;
     }
@@ -128,12 +157,30 @@ struct Source {
         if (fseek(f, (long)at, SEEK_SET) != 0) return 0;
         return fread(dst, 1, len, f);
     }
-    ~Source() { if (own && f) fclose(f); }
+    ~Source() { if (own && f) fclose(f); free(loaded); }
 };
 
 struct Sink {
     uint8_t* mem = nullptr; size_t cap = 0, at = 0; FILE* f = nullptr; bool own = false; bool failed = false;
     bool open_file(const char* path) { f = fopen(path, "wb"); own = true; return f != nullptr; }
+    // file outputs whose bound fits in memory: collect like a memory sink, write once at the end
+    bool open_file_buffered(const char* path, size_t capacity) {
+        if (!open_file(path)) return false;
+        if (capacity <= env_size("TSQ_AMD_FILE_INMEM_MAX", size_t(16) << 30)) {
+            mem = static_cast<uint8_t*>(malloc(capacity ? capacity : 1));
+            if (mem) { cap = capacity; pending_file = f; f = nullptr; }
+        }
+        return true;
+    }
+    bool finish() {
+        if (pending_file) {
+            if (!failed && fwrite(mem, 1, at, pending_file) != at) failed = true;
+            f = pending_file; pending_file = nullptr;
+            free(mem); mem = nullptr;
+        }
+        return !failed;
+    }
+    FILE* pending_file = nullptr;
     bool open_mem(size_t capacity) { mem = static_cast<uint8_t*>(malloc(capacity ? capacity : 1)); cap = capacity; return mem != nullptr; }
     // where the next n bytes will land (memory sinks): the device copies there directly
     uint8_t* claim(size_t n) { if (f || at + n > cap) { failed = true; return nullptr; } uint8_t* p = mem + at; at += n; return p; }
@@ -143,7 +190,7 @@ struct Sink {
         else failed = true;
         at += n;
     }
-    ~Sink() { if (own && f) fclose(f); }
+    ~Sink() { if (pending_file) { fclose(pending_file); free(mem); } else if (own && f) fclose(f); }
 };
 
 // ---- one pipeline lane ----
@@ -288,7 +335,7 @@ private:
         const size_t total = src.size;
         const uint32_t nb = (uint32_t)tsqa_block_count(total);       // tsq_threads.cpp:313
         Sink sink;
-        if (j.outfile) { if (!sink.open_file(j.out_path.c_str())) return false; }
+        if (j.outfile) { if (!sink.open_file_buffered(j.out_path.c_str(), tsqa_container_bound(total))) return false; }
         else if (!sink.open_mem(tsqa_container_bound(total))) return false;   // tsq_threads.cpp:339
 
         uint8_t header[16];                                          // tsq_threads.cpp:333-335,355-359
@@ -299,7 +346,7 @@ private:
         bool ok = true;
         std::deque<InFlight> fly;
         uint32_t done_blocks = 0;
-        const bool stage_in = src.mem == nullptr, stage_out = j.outfile;
+        const bool stage_in = src.mem == nullptr, stage_out = sink.mem == nullptr;
         const uint32_t batch = (stage_in || stage_out) ? file_batch_blocks_ : batch_blocks_;
         Marks mk; mk.at("compress: buffers opened");
         Prefault touch;
@@ -360,7 +407,7 @@ private:
         }
         while (ok && !fly.empty()) drain_one();
         for (auto& l : lanes_) { (void)hipSetDevice(l.dev->device); (void)hipStreamSynchronize(l.dev->stream); }
-        if (sink.failed) ok = false;
+        if (!sink.finish()) ok = false;
         if (!j.outfile) {
             if (ok) { *j.out = sink.mem; *j.szout = sink.at; }       // tsq_threads.cpp:375-379; caller free()s
             else { free(sink.mem); }
@@ -379,13 +426,13 @@ private:
         if (nb == 0) return false;                                                             // tsq_threads.cpp:759-768
         if ((uint64_t)nb * kBlockSize < total) return false;
         Sink sink;
-        if (j.outfile) { if (!sink.open_file(j.out_path.c_str())) return false; }
+        if (j.outfile) { if (!sink.open_file_buffered(j.out_path.c_str(), (size_t)total + 128)) return false; }
         else if (!sink.open_mem((size_t)total + 128)) return false;                            // tsq_threads.cpp:795
 
         bool ok = true;
         std::deque<InFlight> fly;
         uint32_t done_blocks = 0;
-        const bool stage_in = src.mem == nullptr, stage_out = j.outfile;
+        const bool stage_in = src.mem == nullptr, stage_out = sink.mem == nullptr;
         const uint32_t batch = (stage_in || stage_out) ? file_batch_blocks_ : batch_blocks_;
         Prefault touch;
         if (!stage_out) touch.start(sink.mem, (size_t)total);
@@ -453,7 +500,7 @@ private:
         while (ok && !fly.empty()) drain_one();
         for (auto& l : lanes_) { (void)hipSetDevice(l.dev->device); (void)hipStreamSynchronize(l.dev->stream); }
         if (ok && produced != total) ok = false;
-        if (sink.failed) ok = false;
+        if (!sink.finish()) ok = false;
         if (!j.outfile) {
             if (ok) { *j.out = sink.mem; *j.szout = (size_t)total; }
             else { free(sink.mem); }
