@@ -793,10 +793,12 @@ __global__ __launch_bounds__(320) void enc_stage_kernel(const uint8_t* __restric
     }
     __syncthreads();
     lds_u8_t* lds3 = (lds_u8_t*)stage_lds;
-    if (role == 0) stage_scan(src, avail, n, lds3, lane);
-    else if (role == 1) stage_match<EXT>(src, avail, n, table, lds3, lane);
-    else if (role == 2) stage_orbit<EXT>(n, lds3, lane);
-    else if (role == 3) stage_parser<EXT>(src, avail, n, lds3, lane);
+    // Five waves on four SIMDs: waves 0 and 4 share one.  A wave64 VALU instruction occupies its SIMD for four cycles, so the
+    // two that share should not both be VALU-heavy: the parser is almost pure SALU, the builder almost pure VALU.
+    if (role == 0) stage_parser<EXT>(src, avail, n, lds3, lane);
+    else if (role == 1) stage_scan(src, avail, n, lds3, lane);
+    else if (role == 2) stage_match<EXT>(src, avail, n, table, lds3, lane);
+    else if (role == 3) stage_orbit<EXT>(n, lds3, lane);
     else pipe_builder<StageCfg>(src, avail, out, lds3, lane, b, sizes, status);
 }
 
