@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAMES = {0: "(empty: timer cost)", 1: "P wait+loads+prologue", 2: "P orbit+check", 3: "P account", 4: "P resolve", 5: "P flush", 6: "P publish", 7: "P whole segment loop (non-plain tiles)", 8: "P resolve: candidate (twins, LDS words)", 9: "P resolve: decision + outcome", 15: "P plain-tile attempt (both outcomes)", 16: "P whole tile (incl. waiting)",
+NAMES = {0: "(empty: timer cost)", 1: "P wait+loads+prologue", 2: "P orbit+check", 3: "P account", 4: "P resolve", 5: "P flush", 6: "P publish", 7: "P whole segment loop (non-plain tiles)", 8: "P resolve: candidate (twins, LDS words)", 9: "P resolve: decision + outcome", 17: "P after account: masks, tile-end test", 18: "P loop back edge after a hazard",
          10: "M wait scan + record loads", 11: "M wait parser + commit", 12: "M table gather", 13: "M candidate bytes + prefix", 14: "M classify + write + publish"}
 
 if len(sys.argv) > 1 and sys.argv[1] == "--one":

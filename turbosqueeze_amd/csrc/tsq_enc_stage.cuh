@@ -579,7 +579,13 @@ __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail,
             // Costs that shape this loop (one wavefront, measured: tools/micro/issue_rate.hip): ALU instruction 4.5 cycles,
             // branch ~20 cycles taken OR NOT, a VALU result read by the SALU (readlane, ballot) +20 cycles.  So: selects
             // instead of branches, rare cases folded into one test, lane reads batched.
+#ifdef TSQ_STATS
+            unsigned long long back_ = 0;
+#endif
             while (done == 0u) {
+#ifdef TSQ_STATS
+                if (18 == TSQ_REGION && back_) { st_[11] += __builtin_amdgcn_s_memtime() - back_; st_[12] += 1; }
+#endif
                 REG_BEGIN(2);
                 const uint32_t L0 = L;                                           // < 64
                 {
@@ -648,9 +654,11 @@ __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail,
                     }
                 }
                 REG_END(3);
+                REG_BEGIN(17);
                 Vt |= V; Mt |= M;
                 vall |= V;
-                if (L >= 64u) { v = base + L; break; }
+                if (L >= 64u) { v = base + L; REG_END(17); break; }
+                REG_END(17);
                 REG_BEGIN(4);
                 TSQ_CNT(26, 1); TSQ_CNT(27, ((hard >> L) & 1ull) ? 1 : 0);
                 {
@@ -739,6 +747,9 @@ __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail,
                 }
                 L = v - base;
                 REG_END(4);
+#ifdef TSQ_STATS
+                if (18 == TSQ_REGION) back_ = __builtin_amdgcn_s_memtime();
+#endif
                 if (L >= 64u) break;
             }
             REG_BEGIN(5);
