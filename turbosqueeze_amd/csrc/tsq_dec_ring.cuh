@@ -14,6 +14,8 @@
 // which pays for the ring in the 160 KB LDS budget.
 #pragma once
 
+#include <type_traits>
+
 #include "tsq_common.cuh"
 #include "tsq_dec_fast.cuh"      // DecSym, TSQD_* stats macros, g_dec_stats
 
@@ -322,45 +324,49 @@ __global__ __launch_bounds__(RingCfg::T) void dec_ring_kernel(const uint8_t* __r
             for (uint32_t r = 0; r < C::OPER; ++r) if (ptr0[r] != C::RES) plist[at++] = (uint16_t)(tid + r * C::T);
             __syncthreads();
             TSQD_ACC(9);
-            const uint32_t slots = (n_pending + C::T - 1u) / C::T;                          // wave-uniform, usually 3-4 of 12
-            uint32_t q1[C::OPER], p1[C::OPER];
-            uint32_t pending = 0;
+            const uint32_t slots = (n_pending + C::T - 1u) / C::T;                          // block-uniform, usually 3-4 of 12
+            // the rounds, compiled for a fixed number of list slots per lane: with the full 12 every round would pay
+            // for 12 guarded (mostly skipped) bodies per loop
+            auto run_rounds = [&](auto slots_c) {
+                constexpr uint32_t N = decltype(slots_c)::value;
+                uint32_t q1[N], p1[N];
+                uint32_t pending = 0;
 #pragma unroll
-            for (uint32_t r = 0; r < C::OPER; ++r) {
-                q1[r] = 0; p1[r] = C::RES;
-                if (r < slots) { const uint32_t i = tid + r * C::T; if (i < n_pending) { q1[r] = plist[i]; pending |= 1u << r; } }
-            }
-#pragma unroll
-            for (uint32_t r = 0; r < C::OPER; ++r) if ((pending >> r) & 1u) p1[r] = srcp[q1[r]];
-            for (uint32_t round = 0; round < 24; ++round) {
-                ++stamp;
-                const bool wave_pending = __ballot(pending != 0u) != 0ull;
-                if (wave_pending && lane == 0) misc[6] = stamp;
-                __syncthreads();
-                if (misc[6] != stamp) break;
-                TSQD_CNT(13, 1);
-                uint32_t p2[C::OPER], p3[C::OPER], v1[C::OPER], v2[C::OPER];
-#pragma unroll
-                for (uint32_t r = 0; r < C::OPER; ++r) {
-                    p2[r] = C::RES; v1[r] = 0;
-                    if (r < slots) { const uint32_t i1 = (pending >> r) & 1u ? p1[r] : 0u; p2[r] = srcp[i1]; v1[r] = obuf[i1]; }
+                for (uint32_t r = 0; r < N; ++r) {
+                    q1[r] = 0; p1[r] = C::RES;
+                    const uint32_t i = tid + r * C::T;
+                    if (i < n_pending) { q1[r] = plist[i]; pending |= 1u << r; }
                 }
 #pragma unroll
-                for (uint32_t r = 0; r < C::OPER; ++r) {
-                    p3[r] = C::RES; v2[r] = 0;
-                    if (r < slots) { const uint32_t i2 = (((pending >> r) & 1u) && p2[r] != C::RES) ? p2[r] : 0u; p3[r] = srcp[i2]; v2[r] = obuf[i2]; }
-                }
-                __syncthreads();
+                for (uint32_t r = 0; r < N; ++r) if ((pending >> r) & 1u) p1[r] = srcp[q1[r]];
+                for (uint32_t round = 0; round < 24; ++round) {
+                    ++stamp;
+                    const bool wave_pending = __ballot(pending != 0u) != 0ull;
+                    if (wave_pending && lane == 0) misc[6] = stamp;
+                    __syncthreads();
+                    if (misc[6] != stamp) break;
+                    TSQD_CNT(13, 1);
+                    uint32_t p2[N], p3[N], v1[N], v2[N];
 #pragma unroll
-                for (uint32_t r = 0; r < C::OPER; ++r) {
-                    if ((pending >> r) & 1u) {
-                        const uint32_t q = q1[r];
-                        if (p2[r] == C::RES) { obuf[q] = (uint8_t)v1[r]; srcp[q] = C::RES; pending &= ~(1u << r); }
-                        else if (p3[r] == C::RES) { obuf[q] = (uint8_t)v2[r]; srcp[q] = C::RES; pending &= ~(1u << r); }
-                        else { srcp[q] = (uint16_t)p3[r]; p1[r] = p3[r]; }
+                    for (uint32_t r = 0; r < N; ++r) { const uint32_t i1 = (pending >> r) & 1u ? p1[r] : 0u; p2[r] = srcp[i1]; v1[r] = obuf[i1]; }
+#pragma unroll
+                    for (uint32_t r = 0; r < N; ++r) { const uint32_t i2 = (((pending >> r) & 1u) && p2[r] != C::RES) ? p2[r] : 0u; p3[r] = srcp[i2]; v2[r] = obuf[i2]; }
+                    __syncthreads();
+#pragma unroll
+                    for (uint32_t r = 0; r < N; ++r) {
+                        if ((pending >> r) & 1u) {
+                            const uint32_t q = q1[r];
+                            if (p2[r] == C::RES) { obuf[q] = (uint8_t)v1[r]; srcp[q] = C::RES; pending &= ~(1u << r); }
+                            else if (p3[r] == C::RES) { obuf[q] = (uint8_t)v2[r]; srcp[q] = C::RES; pending &= ~(1u << r); }
+                            else { srcp[q] = (uint16_t)p3[r]; p1[r] = p3[r]; }
+                        }
                     }
                 }
-            }
+            };
+            if (slots <= 2u) run_rounds(std::integral_constant<uint32_t, 2>{});
+            else if (slots <= 4u) run_rounds(std::integral_constant<uint32_t, 4>{});
+            else if (slots <= 6u) run_rounds(std::integral_constant<uint32_t, 6>{});
+            else run_rounds(std::integral_constant<uint32_t, C::OPER>{});
         }
         TSQD_ACC(7);
 
