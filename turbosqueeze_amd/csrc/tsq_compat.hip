@@ -276,8 +276,9 @@ public:
             if (!l.init(devs[k % devs.size()])) { l.destroy(); for (auto& x : lanes_) x.destroy(); lanes_.clear(); return false; }
             lanes_.push_back(l);
         }
-        // one batch should fill the device: a block is one workgroup on one CU for its whole (serial) parse
-        batch_blocks_ = (uint32_t)env_size("TSQ_AMD_BATCH_BLOCKS", 256);
+        // one batch should fill the device: a block is one workgroup for its whole (serial) parse, and two of them share a CU
+        // (the encoder's lean layout) at 1.5x the throughput of one
+        batch_blocks_ = (uint32_t)env_size("TSQ_AMD_BATCH_BLOCKS", 512);
         file_batch_blocks_ = (uint32_t)env_size("TSQ_AMD_FILE_BATCH_BLOCKS", batch_blocks_ < 64 ? batch_blocks_ : 64);
         thread_ = std::thread([this] { loop(); });
         return true;
@@ -510,7 +511,7 @@ private:
 
     const bool compress_, verbose_;
     std::vector<Lane> lanes_;
-    uint32_t batch_blocks_ = 256, file_batch_blocks_ = 64;
+    uint32_t batch_blocks_ = 512, file_batch_blocks_ = 64;
     std::thread thread_;
     std::mutex m_;
     std::condition_variable cv_, idle_cv_;

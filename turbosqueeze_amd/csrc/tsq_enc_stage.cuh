@@ -50,6 +50,7 @@ struct StageCfg {
     static constexpr uint32_t off_f = off_ctl + 256;                           // u8[F_MASK + 1]
     static constexpr uint32_t off_win = off_f + F_MASK + 1u;                   // u8[WIN + 32]: the ring, its first 32 bytes mirrored at the end
     static constexpr uint32_t total = off_win + WIN + 32;
+    static constexpr uint32_t total_lean = off_win;                            // without the window: two blocks fit one CU
 };
 // ctl words: 0 queue head, 1 queue tail, 2 tiles scanned, 3 tiles matched, 4 tiles with orbits, 5 tiles parsed,
 //            6 stop, 16 + 2*(t&7): visited mask of tile t (lo, hi)
@@ -110,6 +111,7 @@ __device__ __forceinline__ void stage_publish(lds_u32_t* ctl, uint32_t word, uin
 }
 
 // ---------------------------------------------------------------------------------------------- SCAN
+template <bool WINDOW>
 __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, uint32_t n, lds_u8_t* lds, uint32_t lane)
 {
     volatile lds_u8_t* owner = lds + StageCfg::off_owner;
@@ -168,7 +170,7 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
             u32x4_t v; v.x = w16.x; v.y = w16.y; v.z = w16.z; v.w = w16.w;
             *(volatile lds_u32x4_t*)(rec + StageCfg::W16 + lane * 4u) = v;
             // the tile's 64 input bytes join the window ring MATCH takes candidate bytes from
-            if ((lane & 15u) == 0u) {
+            if (WINDOW && (lane & 15u) == 0u) {
                 *(volatile lds_u32x4_t*)(lds + StageCfg::off_win + wbase + lane) = v;
                 if (wbase == 0u && lane < 32u) *(volatile lds_u32x4_t*)(lds + StageCfg::off_win + StageCfg::WIN + lane) = v;
             }
@@ -190,7 +192,7 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
 }
 
 // --------------------------------------------------------------------------------------------- MATCH
-template <bool EXT>
+template <bool EXT, bool WINDOW>
 __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, uint32_t n, uint16_t* table, lds_u8_t* lds, uint32_t lane)
 {
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
@@ -271,7 +273,7 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         // their 16 bytes come from the window ring in LDS (SCAN has written everything below (t+1)*64); the few lanes whose
         // candidate ends beyond that (closer than 19 bytes to the tile's end) gather from global memory
         uint4 cb;
-        {
+        if (WINDOW) {
             int32_t wi = (int32_t)(wbase + lane) - (int32_t)(p - cand0);
             wi += wi < 0 ? (int32_t)StageCfg::WIN : 0;
             volatile lds_u32_t* wp = (volatile lds_u32_t*)(lds + StageCfg::off_win + ((uint32_t)wi & ~3u));
@@ -280,7 +282,7 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
             cb = make_uint4(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
                             __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh));
             if (cand0 + 19u > ((t + 1u) << 6) || p - cand0 > 65536u) cb = ld128z(src, cand0, avail);
-        }
+        } else cb = ld128z(src, cand0, avail);          // the lean layout (two blocks per CU) has no window: gather from L2
         uint32_t k0 = prefix16(w16, cb);
         MREG_END(13);
         MREG_BEGIN(14);
@@ -777,7 +779,7 @@ __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail,
     }
 }
 
-template <bool EXT>
+template <bool EXT, bool WINDOW>
 __global__ __launch_bounds__(320) void enc_stage_kernel(const uint8_t* __restrict__ in, uint64_t n_total, uint64_t readable,
                                                         uint8_t* __restrict__ slots, uint32_t* __restrict__ sizes,
                                                         uint16_t* __restrict__ tables, int32_t* __restrict__ status)
@@ -807,8 +809,8 @@ __global__ __launch_bounds__(320) void enc_stage_kernel(const uint8_t* __restric
     // Five waves on four SIMDs: waves 0 and 4 share one.  A wave64 VALU instruction occupies its SIMD for four cycles, so the
     // two that share should not both be VALU-heavy: the parser is almost pure SALU, the builder almost pure VALU.
     if (role == 0) stage_parser<EXT>(src, avail, n, lds3, lane);
-    else if (role == 1) stage_scan(src, avail, n, lds3, lane);
-    else if (role == 2) stage_match<EXT>(src, avail, n, table, lds3, lane);
+    else if (role == 1) stage_scan<WINDOW>(src, avail, n, lds3, lane);
+    else if (role == 2) stage_match<EXT, WINDOW>(src, avail, n, table, lds3, lane);
     else if (role == 3) stage_orbit<EXT>(n, lds3, lane);
     else pipe_builder<StageCfg>(src, avail, out, lds3, lane, b, sizes, status);
 }

@@ -24,7 +24,8 @@ inline int launch_encode_fast(tsqa_ctx* c, const uint8_t* in, size_t n, size_t r
     if (rc) return rc;
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[10] = {reinterpret_cast<const void*>(enc_stage_kernel<true>), reinterpret_cast<const void*>(enc_stage_kernel<false>),
+        const void* fns[12] = {reinterpret_cast<const void*>(enc_stage_kernel<true, true>), reinterpret_cast<const void*>(enc_stage_kernel<false, true>),
+                              reinterpret_cast<const void*>(enc_stage_kernel<true, false>), reinterpret_cast<const void*>(enc_stage_kernel<false, false>),
                               reinterpret_cast<const void*>(enc_tile_kernel<true>), reinterpret_cast<const void*>(enc_tile_kernel<false>),
                               reinterpret_cast<const void*>(enc_fast_kernel<true>), reinterpret_cast<const void*>(enc_fast_kernel<false>),
                               reinterpret_cast<const void*>(enc_orbit_kernel<true>), reinterpret_cast<const void*>(enc_orbit_kernel<false>),
@@ -49,8 +50,16 @@ inline int launch_encode_fast(tsqa_ctx* c, const uint8_t* in, size_t n, size_t r
         if (ext) hipLaunchKernelGGL(enc_tile_kernel<true>, dim3(nb), dim3(192), TileCfg::total, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
         else     hipLaunchKernelGGL(enc_tile_kernel<false>, dim3(nb), dim3(192), TileCfg::total, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
     } else {                            // five-wave staged pipeline: scan + match + orbit + parser + builder
-        if (ext) hipLaunchKernelGGL(enc_stage_kernel<true>, dim3(nb), dim3(320), StageCfg::total, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
-        else     hipLaunchKernelGGL(enc_stage_kernel<false>, dim3(nb), dim3(320), StageCfg::total, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
+        // More blocks than CUs: the lean layout (no input window in LDS, candidate bytes from L2) lets two blocks share a CU;
+        // each is a little slower, together they are faster than one after the other.
+        const bool lean = c->enc_variant == 6 || (c->enc_variant == 0 && nb > (uint32_t)c->n_cus);
+        if (lean) {
+            if (ext) hipLaunchKernelGGL((enc_stage_kernel<true, false>), dim3(nb), dim3(320), StageCfg::total_lean, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
+            else     hipLaunchKernelGGL((enc_stage_kernel<false, false>), dim3(nb), dim3(320), StageCfg::total_lean, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
+        } else {
+            if (ext) hipLaunchKernelGGL((enc_stage_kernel<true, true>), dim3(nb), dim3(320), StageCfg::total, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
+            else     hipLaunchKernelGGL((enc_stage_kernel<false, true>), dim3(nb), dim3(320), StageCfg::total, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
+        }
     }
     return 0;
 }
