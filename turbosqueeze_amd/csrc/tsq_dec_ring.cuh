@@ -237,44 +237,61 @@ __global__ __launch_bounds__(RingCfg::T) void dec_ring_kernel(const uint8_t* __r
         __syncthreads();
         TSQD_ACC(4);
 
-        // ---------------- P5: symbol records, one lane per group
-        if (tid < ng) {
-            const uint32_t x = gstart[tid];
+        // ---------------- P5: symbol records, one lane per PAIR (four lanes per group).  A pair's stream position and output
+        // position follow from the pairs before it, so its lane first walks those (sizes only); that is redundant work, but
+        // the phase is a chain of dependent LDS reads, and a quarter of the lanes doing four pairs each took twice as long.
+        for (uint32_t gi = tid; gi < ng * 4u; gi += C::T) {
+            const uint32_t g = gi >> 2, mine = gi & 3u;
+            const uint32_t x = gstart[g];
             const uint32_t c = sbuf[x];
-            uint32_t p = x + 1, j = gout[tid];
-            uint32_t bad = 0;
-            DecSym* rec = syms + tid * 8u;
+            uint32_t p = x + 1, j = gout[g];
+            for (uint32_t pr = 0; pr < mine; ++pr) {                      // the pairs in front: only how far they move p and j
+                if (j < size) {
+                    const uint32_t sb = sbuf[p];
+                    p++;
 #pragma unroll
-            for (uint32_t pr = 0; pr < 4; ++pr) {
-                uint32_t sb = 0;
-                const uint32_t origin = j;
-                if (j < size) { if (p >= avail) bad = 1; sb = sbuf[p]; p++; }
-#pragma unroll
-                for (uint32_t s = 0; s < 2; ++s) {
-                    DecSym r; r.out_rel = 0; r.len = 0; r.kind = 0; r.a = 0;
-                    if (j < size && !bad) {
-                        const uint32_t nib = s == 0 ? sb >> 4 : sb & 15u;
-                        const uint32_t lit = (c >> (7u - (2u * pr + s))) & 1u;
-                        const uint32_t room = size - j;
-                        if (lit) {
-                            const uint32_t len = nib + 1u, take = len < room ? len : room;
-                            if (p + take > avail) bad = 1;
-                            r.out_rel = (uint16_t)(j - op); r.len = (uint8_t)take; r.kind = 1; r.a = p;
-                            p += len; j += take;
-                        } else {
-                            if (p + 2u > avail) bad = 1;
-                            const uint32_t off = (uint32_t)sbuf[p] | ((uint32_t)sbuf[p + 1] << 8);
-                            p += 2;
-                            const uint32_t len = (ext && nib < 3u) ? (nib + 2u) << 4 : nib + 1u;
-                            const uint32_t take = len < room ? len : room;
-                            if (off > origin || take > off) bad = 1;
-                            r.out_rel = (uint16_t)(j - op); r.len = (uint8_t)take; r.kind = 2; r.a = origin - off;
-                            j += take;
+                    for (uint32_t sidx = 0; sidx < 2; ++sidx) {
+                        if (j < size) {
+                            const uint32_t nib = sidx == 0 ? sb >> 4 : sb & 15u;
+                            const uint32_t lit = (c >> (7u - (2u * pr + sidx))) & 1u;
+                            const uint32_t room = size - j;
+                            const uint32_t len = lit ? nib + 1u : ((ext && nib < 3u) ? (nib + 2u) << 4 : nib + 1u);
+                            p += lit ? len : 2u;
+                            j += len < room ? len : room;
                         }
-                        if (bad) r.kind = 0;
                     }
-                    rec[pr * 2u + s] = r;
                 }
+            }
+            uint32_t bad = 0;
+            DecSym* rec = syms + g * 8u + mine * 2u;
+            uint32_t sb = 0;
+            const uint32_t origin = j;
+            if (j < size) { if (p >= avail) bad = 1; sb = sbuf[p]; p++; }
+#pragma unroll
+            for (uint32_t sidx = 0; sidx < 2; ++sidx) {
+                DecSym r; r.out_rel = 0; r.len = 0; r.kind = 0; r.a = 0;
+                if (j < size && !bad) {
+                    const uint32_t nib = sidx == 0 ? sb >> 4 : sb & 15u;
+                    const uint32_t lit = (c >> (7u - (2u * mine + sidx))) & 1u;
+                    const uint32_t room = size - j;
+                    if (lit) {
+                        const uint32_t len = nib + 1u, take = len < room ? len : room;
+                        if (p + take > avail) bad = 1;
+                        r.out_rel = (uint16_t)(j - op); r.len = (uint8_t)take; r.kind = 1; r.a = p;
+                        p += len; j += take;
+                    } else {
+                        if (p + 2u > avail) bad = 1;
+                        const uint32_t off = (uint32_t)sbuf[p] | ((uint32_t)sbuf[p + 1] << 8);
+                        p += 2;
+                        const uint32_t len = (ext && nib < 3u) ? (nib + 2u) << 4 : nib + 1u;
+                        const uint32_t take = len < room ? len : room;
+                        if (off > origin || take > off) bad = 1;
+                        r.out_rel = (uint16_t)(j - op); r.len = (uint8_t)take; r.kind = 2; r.a = origin - off;
+                        j += take;
+                    }
+                    if (bad) r.kind = 0;
+                }
+                rec[sidx] = r;
             }
             if (bad) misc[4] = kErrStream;
         }
