@@ -118,8 +118,8 @@ int tsqa_profile_read(tsqa_ctx *ctx, double *encode_ms, uint32_t *encode_launche
 /* Kernel variant selection for A/B measurements: 0 = default (five-wave staged encoder, ring decoder),
  * 1 = serial kernels (one lane walks the block; correctness baseline), 2 = windowed scalar-walk encoder /
  * chunked decoder without history ring, and encode only: 3 = single-wave orbit, 4 = two-wave
- * parser/builder, 5 = three-wave tile pipeline, 6 = the staged encoder's lean layout (no input window in LDS, two
- * blocks per CU; variant 0 picks it by itself when there are more blocks than CUs), 7 = staged, never lean. */
+ * parser/builder, 5 = three-wave tile pipeline, 6 = the lean layouts (encoder without the input window, decoder without the history ring: two
+ * blocks per CU; variant 0 picks them by itself when there are more blocks than CUs), 7 = never lean. */
 void tsqa_set_kernel_variant(tsqa_ctx *ctx, int encode_variant, int decode_variant);
 
 /* =====================================================================================

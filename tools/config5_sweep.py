@@ -12,7 +12,8 @@ ext = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 variant = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 kinds = sys.argv[4].split(',') if len(sys.argv) > 4 else ("zeros", "random", "mix", "text")
 codec = tsq.DeviceCodec(0)
-codec.set_variant(variant, 0)
+dec_variant = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+codec.set_variant(variant, dec_variant)
 for kind in kinds:
     host = {"zeros": lambda: np.zeros(n, dtype=np.uint8), "random": lambda: tsq.synth.random_bytes(n, 3),
             "mix": lambda: tsq.synth.mix(n, 3), "text": lambda: tsq.synth.text(n, 3)}[kind]()
@@ -28,6 +29,6 @@ for kind in kinds:
         codec.decompress_async(out, nb, back); torch.cuda.synchronize()
     em, en, dm, dn = codec.profile_read(); codec.profile(False)
     assert torch.equal(back, src)
-    print(json.dumps({"input": kind, "bytes": n, "ext": ext, "encode_variant": variant, "ratio": round(csz / n, 4),
+    print(json.dumps({"input": kind, "bytes": n, "ext": ext, "encode_variant": variant, "decode_variant": dec_variant, "ratio": round(csz / n, 4),
                       "encode_GBps": round(n / (em / en * 1e-3) / 1e9, 2), "decode_GBps": round(n / (dm / dn * 1e-3) / 1e9, 2)}))
     del src, out, back

@@ -21,47 +21,60 @@
 
 namespace tsq {
 
-struct RingCfg {
+// RING_ON: the standard layout (64 KiB history ring, 6 KiB chunks, ~150 KB of LDS: one block per CU).
+// !RING_ON: the lean layout for more blocks than CUs -- no ring (history bytes are gathered from the block's own output in
+// L2), 5 KiB chunks, ~71 KB of LDS: two blocks share a CU.
+template <bool RING_ON>
+struct RingCfgT {
     static constexpr uint32_t T = 1024;
-    static constexpr uint32_t S = 6144;        // stream bytes per chunk
+    static constexpr uint32_t S = RING_ON ? 6144 : 5120;   // stream bytes per chunk
     static constexpr uint32_t SPAD = 160;
-    static constexpr uint32_t OUTC = 12288;    // output bytes per chunk image
+    static constexpr uint32_t OUTC = 2 * S;    // output bytes per chunk image
     static constexpr uint32_t D = 4;
     static constexpr uint32_t HOP = 1u << D;
-    static constexpr uint32_t MAXG = 544;      // >= S / 13 + 2 * HOP
+    static constexpr uint32_t MAXG = RING_ON ? 544 : 448;  // >= S / 13 + 2 * HOP
     static constexpr uint32_t MAXSN = MAXG / HOP + 2;
-    static constexpr uint32_t PER = S / T;     // offsets per lane (6)
-    static constexpr uint32_t OPER = OUTC / T; // image bytes per lane (12)
+    static constexpr uint32_t PER = S / T;     // offsets per lane
+    static constexpr uint32_t OPER = OUTC / T; // image bytes per lane
     static constexpr uint16_t RES = 0xFFFF;
-    static constexpr uint32_t RING = 65536;
+    static constexpr uint32_t RING = RING_ON ? 65536 : 0;
 };
-struct RingLds {
+template <class Cfg>
+struct RingLdsT {
     static constexpr uint32_t sbuf = 0;                                          // S + SPAD + 32
-    static constexpr uint32_t nx1 = sbuf + RingCfg::S + RingCfg::SPAD + 32;      // u16[S]
-    static constexpr uint32_t ja = nx1 + 2 * RingCfg::S;
-    static constexpr uint32_t jb = ja + 2 * RingCfg::S;
+    static constexpr uint32_t nx1 = sbuf + Cfg::S + Cfg::SPAD + 32;              // u16[S]
+    static constexpr uint32_t ja = nx1 + 2 * Cfg::S;
+    static constexpr uint32_t jb = ja + 2 * Cfg::S;
     static constexpr uint32_t syms = nx1;                                        // DecSym[8 * MAXG] over nx1, ja, jb (dead after P4)
-    static constexpr uint32_t srcp = jb + 2 * RingCfg::S;                        // u16[OUTC + 16]
-    static constexpr uint32_t obuf = srcp + 2 * (RingCfg::OUTC + 16);            // u8[OUTC + 32]
-    static constexpr uint32_t ring = obuf + RingCfg::OUTC + 32;                  // u8[65536]
-    static constexpr uint32_t gstart = ring + RingCfg::RING;                     // u16[MAXG]
-    static constexpr uint32_t glen = gstart + 2 * RingCfg::MAXG;                 // u16[MAXG]
-    static constexpr uint32_t gout = glen + 2 * RingCfg::MAXG;                   // u32[MAXG]
-    static constexpr uint32_t sn = gout + 4 * RingCfg::MAXG;                     // u16[MAXSN + pad]
-    static constexpr uint32_t wsum = sn + 2 * ((RingCfg::MAXSN + 7) & ~7u);
+    static constexpr uint32_t srcp = jb + 2 * Cfg::S;                            // u16[OUTC + 16]
+    static constexpr uint32_t obuf = srcp + 2 * (Cfg::OUTC + 16);                // u8[OUTC + 32]
+    static constexpr uint32_t ring = obuf + Cfg::OUTC + 32;                      // u8[RING]
+    static constexpr uint32_t gstart = ring + Cfg::RING;                         // u16[MAXG]
+    static constexpr uint32_t glen = gstart + 2 * Cfg::MAXG;                     // u16[MAXG]
+    static constexpr uint32_t gout = glen + 2 * Cfg::MAXG;                       // u32[MAXG]
+    static constexpr uint32_t sn = gout + 4 * Cfg::MAXG;                         // u16[MAXSN + pad]
+    static constexpr uint32_t wsum = sn + 2 * ((Cfg::MAXSN + 7) & ~7u);
     static constexpr uint32_t misc = wsum + 64;
     static constexpr uint32_t total = misc + 64;
+    static_assert(8 * Cfg::MAXG * sizeof(DecSym) <= 6 * Cfg::S, "symbol records must fit the dead tables");
+    static_assert(Cfg::S % Cfg::T == 0 && Cfg::OUTC % Cfg::T == 0, "per-lane item counts");
+    static_assert(Cfg::MAXG >= Cfg::S / 13 + 2 * Cfg::HOP, "group table");
 };
-static_assert(8 * RingCfg::MAXG * sizeof(DecSym) <= 6 * RingCfg::S, "symbol records must fit the dead tables");
+using RingCfg = RingCfgT<true>;
+using RingLds = RingLdsT<RingCfg>;
+using LeanCfg = RingCfgT<false>;
+using LeanLds = RingLdsT<LeanCfg>;
 static_assert(RingLds::total <= 160 * 1024, "LDS budget");
-static_assert(RingCfg::S % RingCfg::T == 0 && RingCfg::OUTC % RingCfg::T == 0, "per-lane item counts");
+static_assert(2 * LeanLds::total <= 160 * 1024, "two lean blocks per CU");
 
-__global__ __launch_bounds__(RingCfg::T) void dec_ring_kernel(const uint8_t* __restrict__ container,
+template <bool RING_ON>
+__global__ __launch_bounds__(1024, RING_ON ? 4 : 8) void dec_ring_kernel(const uint8_t* __restrict__ container,
                                                               const FrameInfo* __restrict__ frames,
                                                               uint8_t* __restrict__ outbuf,
                                                               int32_t* __restrict__ status)
 {
-    using C = RingCfg;
+    using C = RingCfgT<RING_ON>;
+    using RingLds = RingLdsT<C>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t* const s_raw = lds + RingLds::sbuf;
     uint16_t* const nx1 = reinterpret_cast<uint16_t*>(lds + RingLds::nx1);
@@ -307,7 +320,7 @@ __global__ __launch_bounds__(RingCfg::T) void dec_ring_kernel(const uint8_t* __r
             } else if (r.kind == 2) {
                 for (uint32_t t = 0; t < r.len; ++t) {
                     const uint32_t a = r.a + t, q = r.out_rel + t;
-                    if (a < op) obuf[q] = ring[a & (C::RING - 1u)];
+                    if (a < op) obuf[q] = RING_ON ? ring[a & (C::RING - 1u)] : out[a];
                     else srcp[q] = (uint16_t)(a - op);
                 }
             }
@@ -391,17 +404,18 @@ __global__ __launch_bounds__(RingCfg::T) void dec_ring_kernel(const uint8_t* __r
         {
             const uint32_t head = (16u - oskew) & 15u;
             const uint32_t hb = head < image_len ? head : image_len;
-            if (tid < hb) { out[op + tid] = obuf[tid]; ring[(op + tid) & (C::RING - 1u)] = obuf[tid]; }
+            if (tid < hb) { out[op + tid] = obuf[tid]; if (RING_ON) ring[(op + tid) & (C::RING - 1u)] = obuf[tid]; }
             const uint32_t words = image_len > hb ? (image_len - hb) >> 4 : 0;
             for (uint32_t w = tid; w < words; w += C::T) {
                 const uint4 v = *reinterpret_cast<const uint4*>(obuf + hb + (w << 4));
                 *reinterpret_cast<uint4*>(out + op + hb + (w << 4)) = v;
                 const uint32_t ri = (op + hb + (w << 4)) & (C::RING - 1u);
-                if (out_aligned) *reinterpret_cast<uint4*>(ring + ri) = v;     // same 16-byte phase as the output address
+                if (!RING_ON) {}
+                else if (out_aligned) *reinterpret_cast<uint4*>(ring + ri) = v;     // same 16-byte phase as the output address
                 else { const uint32_t wd[4] = {v.x, v.y, v.z, v.w}; for (uint32_t t = 0; t < 16; ++t) ring[(ri + t) & (C::RING - 1u)] = (uint8_t)(wd[t >> 2] >> (8u * (t & 3u))); }
             }
             const uint32_t tail_at = hb + (words << 4);
-            if (tid < image_len - tail_at) { out[op + tail_at + tid] = obuf[tail_at + tid]; ring[(op + tail_at + tid) & (C::RING - 1u)] = obuf[tail_at + tid]; }
+            if (tid < image_len - tail_at) { out[op + tail_at + tid] = obuf[tail_at + tid]; if (RING_ON) ring[(op + tail_at + tid) & (C::RING - 1u)] = obuf[tail_at + tid]; }
         }
         __syncthreads();
         op = next_op;

@@ -69,7 +69,8 @@ inline int launch_decode_fast(tsqa_ctx* c, const uint8_t* container, uint32_t n_
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DecLds::total) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(dec_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RingLds::total) != hipSuccess) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(dec_ring_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RingLds::total) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(dec_ring_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LeanLds::total) != hipSuccess) {
             c->set_error("cannot reserve LDS for the decoder");
             return TSQA_ERR_HIP;
         }
@@ -78,7 +79,11 @@ inline int launch_decode_fast(tsqa_ctx* c, const uint8_t* container, uint32_t n_
     if (c->dec_variant == 2)   // the first parallel decoder (history gathered from L2), kept for A/B
         hipLaunchKernelGGL(dec_fast_kernel, dim3(n_blocks), dim3(DecCfg::T), DecLds::total, s, container, c->frames, out, status);
     else
-        hipLaunchKernelGGL(dec_ring_kernel, dim3(n_blocks), dim3(RingCfg::T), RingLds::total, s, container, c->frames, out, status);
+        // more blocks than CUs: the lean layout lets two blocks share a CU (variant 6 forces it, 7 never uses it)
+        if (c->dec_variant == 6 || (c->dec_variant == 0 && n_blocks > (uint32_t)c->n_cus))
+            hipLaunchKernelGGL(dec_ring_kernel<false>, dim3(n_blocks), dim3(LeanCfg::T), LeanLds::total, s, container, c->frames, out, status);
+        else
+            hipLaunchKernelGGL(dec_ring_kernel<true>, dim3(n_blocks), dim3(RingCfg::T), RingLds::total, s, container, c->frames, out, status);
     return 0;
 }
 
