@@ -1,6 +1,8 @@
 // tsq_fast.cuh -- the production encode/decode kernels (variant 0).
 #pragma once
 
+#include <atomic>
+
 #include "tsq_common.cuh"
 #include "tsq_emit.cuh"
 #include "tsq_internal.h"
@@ -22,8 +24,10 @@ inline int launch_encode_fast(tsqa_ctx* c, const uint8_t* in, size_t n, size_t r
     const uint32_t nb = (uint32_t)((n + kBlockSize - 1) / kBlockSize);
     int rc = c->reserve(nb, true);
     if (rc) return rc;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the dynamic-LDS limit is a per-device attribute of the function: once per device the process uses
+    static std::atomic<uint64_t> attr_devices{0};
+    const uint64_t dev_bit = 1ull << (c->device & 63);
+    if (!(attr_devices.load() & dev_bit)) {
         const void* fns[12] = {reinterpret_cast<const void*>(enc_stage_kernel<true, true>), reinterpret_cast<const void*>(enc_stage_kernel<false, true>),
                               reinterpret_cast<const void*>(enc_stage_kernel<true, false>), reinterpret_cast<const void*>(enc_stage_kernel<false, false>),
                               reinterpret_cast<const void*>(enc_tile_kernel<true>), reinterpret_cast<const void*>(enc_tile_kernel<false>),
@@ -35,7 +39,7 @@ inline int launch_encode_fast(tsqa_ctx* c, const uint8_t* in, size_t n, size_t r
                 c->set_error("cannot reserve %u B of LDS", kEncMaxLds);
                 return TSQA_ERR_HIP;
             }
-        attr_set = true;
+        attr_devices.fetch_or(dev_bit);
     }
     if (c->enc_variant == 2) {          // the windowed scalar walk (kept for A/B)
         if (ext) hipLaunchKernelGGL(enc_fast_kernel<true>, dim3(nb), dim3(64), kEncLds, s, in, (uint64_t)n, (uint64_t)readable, c->slots, c->sizes, c->tables, status);
@@ -66,15 +70,17 @@ inline int launch_encode_fast(tsqa_ctx* c, const uint8_t* in, size_t n, size_t r
 
 inline int launch_decode_fast(tsqa_ctx* c, const uint8_t* container, uint32_t n_blocks, uint8_t* out, int32_t* status, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the dynamic-LDS limit is a per-device attribute of the function: once per device the process uses
+    static std::atomic<uint64_t> attr_devices{0};
+    const uint64_t dev_bit = 1ull << (c->device & 63);
+    if (!(attr_devices.load() & dev_bit)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DecLds::total) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(dec_ring_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RingLds::total) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(dec_ring_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LeanLds::total) != hipSuccess) {
             c->set_error("cannot reserve LDS for the decoder");
             return TSQA_ERR_HIP;
         }
-        attr_set = true;
+        attr_devices.fetch_or(dev_bit);
     }
     if (c->dec_variant == 2)   // the first parallel decoder (history gathered from L2), kept for A/B
         hipLaunchKernelGGL(dec_fast_kernel, dim3(n_blocks), dim3(DecCfg::T), DecLds::total, s, container, c->frames, out, status);
