@@ -189,6 +189,36 @@ def test_enwik9_sized_roundtrip_properties(codec, oracle, tsq):
         assert bytes(raw[s:s + ln]) == want, b
 
 
+def test_more_blocks_than_cus_lean_layouts(codec, oracle, tsq):
+    """More blocks than CUs (1.25 GiB = 320 blocks, a 10 GiB / 8 GPU shard of BASELINE.json config 5): the default kernels
+    switch to their lean layouts (two blocks per CU).  Round trip identity, with extensions, on the 50 % mix, and sampled
+    blocks against the oracle."""
+    import torch
+    n = 5 * (1 << 28) + 12345
+    nb = (n + (1 << 22) - 1) >> 22
+    host = tsq.synth.mix(n, seed=13)
+    dev = to_dev(host)
+    blob = codec.compress(dev, 1)
+    back = codec.decompress(blob)
+    assert torch.equal(back, dev)
+    del back
+    raw = blob.cpu().numpy()
+    assert int.from_bytes(bytes(raw[4:8]), "little") == nb
+    at, frames = 16, []
+    for _ in range(nb):
+        ln = int(raw[at]) | int(raw[at + 1]) << 8 | (int(raw[at + 2]) & 0x7F) << 16
+        assert int(raw[at + 2]) >> 7 == 1                      # the extension flag of the frame
+        frames.append((at + 3, ln))
+        at += 3 + ln
+    assert at == raw.size
+    for b in (0, 200, nb - 1):
+        lo = b << 22
+        hi = min(n, lo + (1 << 22))
+        want = oracle.encode_block(host[lo:hi], 1, halo=bytes(host[hi:hi + 128]))
+        s0, ln = frames[b]
+        assert bytes(raw[s0:s0 + ln]) == want, b
+
+
 def test_container_errors(codec, tsq, oracle):
     good = oracle.compress(tsq.synth.text(300000, 2), 0)
     bad_magic = b"TSQ2" + good[4:]
