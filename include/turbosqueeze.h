@@ -7,19 +7,68 @@
  * The codec itself runs as HIP kernels on an MI355X; see include/turbosqueeze_amd.h for the plain
  * C ABI underneath and for the device-resident entry points.
  *
- * The reference exposes its thread-pool internals (TSQBuffer, TSQWorker, TSQJob) in the header;
- * callers only ever receive context pointers from the library, so those are not reproduced.
- * What callers do touch is kept: TSQCompressionContext::refhash (test/test.cpp:42) and the
- * leading num_cores field of both _MT contexts (turbosqueeze.h:343,404).
+ * What callers touch is kept: TSQCompressionContext::refhash (test/test.cpp:42) and the leading
+ * num_cores field of both _MT contexts (turbosqueeze.h:343,404).  The reference also shows its
+ * thread-pool records (TSQBuffer, TSQWorker, TSQJob; turbosqueeze.h:81-316) in the header.  No entry
+ * point takes or returns them and the HIP stream scheduler has no use for them, but a program that
+ * names them still compiles: they are declared below with the reference's member names and types.
  */
 #pragma once
 
+#include <condition_variable>
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <functional>
+#include <mutex>
+#include <vector>
 
 #include "turbosqueeze_amd.h"
+
+/* ---- records of the reference's thread pool (turbosqueeze.h:81-106,129-188,215-316).  Never created or
+ *      consumed by this library; present for source compatibility only. ---- */
+class TSQJob;
+struct TSQBuffer {                       /* one slot of a worker's input or output ring */
+    uint8_t* buffer = nullptr;
+    uint8_t* filebuffer = nullptr;
+    TSQJob* job = nullptr;
+    uint32_t size = 0, ext = 0, compression_level = 0;
+};
+struct TSQWorker {                       /* a worker's two rings and their hand-off counters */
+    std::vector<TSQBuffer> inputs;
+    uint32_t n_inputs = 0;
+    volatile uint64_t currentReadInput = 0, currentWorkInput = 0;
+    std::mutex input_mtx;
+    std::condition_variable input_cv;
+    std::vector<TSQBuffer> outputs;
+    uint32_t n_outputs = 0;
+    volatile uint64_t currentWorkOutput = 0, currentWriteOutput = 0;
+    std::mutex output_mtx;
+    std::condition_variable output_cv;
+    uint32_t blocksPerWorker = 0;
+};
+class TSQJob {                           /* one queued compress / decompress request */
+public:
+    ~TSQJob() {
+        if (input_file && input_stream) fclose(input_stream);
+        if (output_file && output_stream) fclose(output_stream);
+    }
+    uint8_t* input = nullptr;
+    uint64_t size = 0;
+    bool input_file = false;
+    uint32_t jobid = 0;
+    bool use_extensions = false;
+    uint32_t compression_level = 0;
+    FILE* input_stream = nullptr;
+    uint64_t input_size = 0, start_block = 0, n_blocks = 0;
+    uint8_t* output = nullptr;
+    uint64_t outsize = 0;
+    bool output_file = false;
+    FILE* output_stream = nullptr;
+    bool error_occurred = false;
+    std::function<void(uint32_t jobid, bool)> completion_cb;
+    std::function<void(uint32_t jobid, double)> progress_cb;
+};
 
 /* Both _MT contexts: `num_cores` is what the reference calls its worker count; here it is the
  * number of compute units of the device the context drives.  Everything else is private. */

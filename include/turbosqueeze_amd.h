@@ -57,7 +57,10 @@ enum {
 
 typedef struct tsqa_ctx tsqa_ctx;   /* one per (process, device): streams + scratch in HBM */
 
-/* device < 0: use the current HIP device.  Scratch is grown on demand and kept. */
+/* device < 0: use the current HIP device.  Scratch is grown on demand and kept.
+ * A context owns ONE set of scratch buffers (block slots, sizes, frame tables): calls on the same context must be
+ * ordered on one stream at a time -- issue the next call on the same stream, or after the previous one has drained.
+ * Two streams that want to run concurrently take two contexts. */
 int         tsqa_create(int device, tsqa_ctx **out);
 void        tsqa_destroy(tsqa_ctx *ctx);
 const char *tsqa_last_error(const tsqa_ctx *ctx);
@@ -107,6 +110,46 @@ int tsqa_decompress_device_async(tsqa_ctx *ctx, const void *d_in, size_t n, uint
                                  void *d_out, size_t out_cap, uint64_t *d_out_size,
                                  int32_t *d_status, void *hip_stream);
 
+/*
+ * Sharded operation: blocks are independent, so a job can be cut across devices or ranks --
+ * block i -> worker i % num_cores in the reference (tsq_threads.cpp:71,463).  These two entry points work on
+ * whatever subset of a job's blocks a device owns and leave the gather (frames in block order,
+ * tsq_threads.cpp:192-275; blocks at their offsets, :648) to the caller.
+ *
+ * tsqa_encode_blocks_async: block b of the call is read at d_in + b * stride; every block is TSQ_BLOCK_SZ long
+ * except the last (last_len), and each is IMMEDIATELY followed by its look-ahead bytes (the first 128 bytes of
+ * the block that follows it in the job; zeros after the job's last block) -- so stride = TSQ_BLOCK_SZ for one
+ * contiguous buffer, TSQ_BLOCK_SZ + 128 for a shard that holds every N-th block.  Stream b lands at
+ * d_slots + b * TSQ_OUTPUT_SZ, its size in d_sizes[b] (both device memory).  Replaces tsqInit + tsqEncode per
+ * owned block (tsq_threads.cpp:176-177).
+ */
+int tsqa_encode_blocks_async(tsqa_ctx *ctx, const void *d_in, uint32_t n_blocks, size_t stride, uint32_t last_len,
+                             uint32_t ext, void *d_slots, uint32_t *d_sizes, int32_t *d_status, void *hip_stream);
+
+/* One block stream to decode: where it starts (relative to d_streams), where its bytes go (relative to d_out). */
+typedef struct tsqa_frame {
+    uint64_t stream_at;   /* first byte of the block stream (the u24 size header) */
+    uint64_t out_at;      /* where the decoded block goes */
+    uint32_t stream_len;  /* frame & 0x7FFFFF (tsq_threads.cpp:513-517) */
+    uint32_t ext;         /* frame >> 23 */
+    uint32_t out_len;     /* the stream's u24 header: decoded bytes (<= TSQ_BLOCK_SZ) */
+    uint32_t pad;
+} tsqa_frame;
+
+/* tsqa_decode_blocks_async: decode n_blocks streams described by d_frames (device memory).  Replaces tsqDecode
+ * per owned block (tsq_threads.cpp:590).  *d_status becomes TSQA_ERR_STREAM on a malformed stream. */
+int tsqa_decode_blocks_async(tsqa_ctx *ctx, const void *d_streams, const tsqa_frame *d_frames, uint32_t n_blocks,
+                             void *d_out, int32_t *d_status, void *hip_stream);
+
+/* The gather / scatter that goes with them: one DMA per owned block between its slot in HBM (b * TSQ_OUTPUT_SZ) and
+ * its frame in a container in HOST memory (pinned or hipHostRegister'ed for full DMA speed).  frame_at[b] is the
+ * container offset of block b's three frame bytes (16 + sum over earlier blocks of 3 + size); sizes and frame_at are
+ * host arrays.  to_host also writes the frame bytes (size | ext << 23, tsq_threads.cpp:218-219). */
+int tsqa_frames_to_host_async(tsqa_ctx *ctx, const void *d_slots, const uint32_t *sizes, const uint64_t *frame_at,
+                              uint32_t n_blocks, uint32_t ext, void *host_container, void *hip_stream);
+int tsqa_frames_from_host_async(tsqa_ctx *ctx, const void *host_container, const uint64_t *frame_at, const uint32_t *sizes,
+                                uint32_t n_blocks, void *d_streams, void *hip_stream);
+
 /* Kernel timing for bench.py: when enabled, every encode / decode kernel launch is bracketed by
  * HIP events recorded on the stream it is launched on (up to 256 launches are kept).
  * tsqa_profile_read waits for those events and returns, per kernel, the summed elapsed
@@ -114,12 +157,20 @@ int tsqa_decompress_device_async(tsqa_ctx *ctx, const void *d_in, size_t n, uint
 int tsqa_profile_enable(tsqa_ctx *ctx, int on);
 int tsqa_profile_read(tsqa_ctx *ctx, double *encode_ms, uint32_t *encode_launches,
                       double *decode_ms, uint32_t *decode_launches);
+/* The same for whole calls: tsqa_compress_device_async (encode kernel + container pack) and
+ * tsqa_decompress_device_async (frame walk + decode kernel). */
+int tsqa_profile_read_calls(tsqa_ctx *ctx, double *compress_ms, uint32_t *compress_calls,
+                            double *decompress_ms, uint32_t *decompress_calls);
 
-/* Kernel variant selection for A/B measurements: 0 = default (five-wave staged encoder, ring decoder),
- * 1 = serial kernels (one lane walks the block; correctness baseline), 2 = windowed scalar-walk encoder /
- * chunked decoder without history ring, and encode only: 3 = single-wave orbit, 4 = two-wave
- * parser/builder, 5 = three-wave tile pipeline, 6 = the lean layouts (encoder without the input window, decoder without the history ring: two
- * blocks per CU; variant 0 picks them by itself when there are more blocks than CUs), 7 = never lean. */
+/* The measured copy bandwidth of this GPU (bytes read + bytes written per second, GB/s = 1e9 B/s) by a plain
+ * grid-stride 16-byte copy kernel over `bytes` of HBM: the second denominator beside the 8 TB/s specification when a
+ * kernel is priced against the HBM roofline. */
+int tsqa_measure_copy(tsqa_ctx *ctx, size_t bytes, int reps, double *best_gbps, double *median_gbps);
+
+/* Kernel variant selection: 0 = default (five-wave staged encoder, ring decoder; lean layouts by themselves when
+ * there are more blocks than CUs), 1 = serial kernels (one lane walks the block; correctness baseline), 6 = force the
+ * lean layouts (two blocks per CU), 7 = never lean.  Variants 2-5 (superseded kernel generations) exist only in the
+ * A/B library built by `make ab`; the product library rejects them. */
 void tsqa_set_kernel_variant(tsqa_ctx *ctx, int encode_variant, int decode_variant);
 
 /* =====================================================================================
@@ -139,7 +190,10 @@ void tsqDeallocateContext(struct TSQCompressionContext *ctx);
 void tsqInit(struct TSQCompressionContext *ctx);
 
 /* turbosqueeze.h:657 -- one block, synchronous.  inputSize <= TSQ_BLOCK_SZ; outputBlock must
- * hold TSQ_OUTPUT_SZ bytes.  The look-ahead past inputBlock[inputSize-1] sees zeros. */
+ * hold TSQ_OUTPUT_SZ bytes.  As in the reference (tsq_encode.cpp:74,108,126,162; its scheduler hands workers pointers
+ * into the caller's contiguous buffer, tsq_threads.cpp:109) the encoder looks up to 128 bytes past
+ * inputBlock[inputSize-1]: what is readable there is used (so a loop over the blocks of one buffer gives the
+ * reference's bytes), what is not mapped is seen as zeros instead of faulting. */
 void tsqEncode(struct TSQCompressionContext *ctx, uint8_t *inputBlock, uint8_t *outputBlock,
                uint32_t *outputSize, uint32_t inputSize, uint32_t withExtensions);
 /* turbosqueeze.h:670 -- *outputSize = 0 on an oversize header or a malformed stream. */

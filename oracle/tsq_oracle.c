@@ -5,10 +5,11 @@
  * specification in SURVEY.md section 8a; every function cites the reference
  * lines whose behaviour it restates.  Plain C11, no dependencies.
  */
-#define _POSIX_C_SOURCE 200809L   /* pthread barriers, clock_gettime */
+#define _GNU_SOURCE               /* pthread barriers, clock_gettime, pthread_setaffinity_np, CPU_SET */
 #include "tsq_oracle.h"
 
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <time.h>
 #include <string.h>
@@ -415,14 +416,24 @@ uint64_t tsqo_fnv1a64(const uint8_t *p, size_t n)
 }
 
 /* -------------------------------------------------------------------------
- * CPU baseline driver for bench.py: block-parallel encode then decode of one
- * buffer with a persistent pthread pool (block b -> thread b % T, the
- * reference's assignment, tsq_threads.cpp:71), wall-clock per phase, best of
- * `reps` after one untimed warm pass (page faults).  `enc`/`dec` are the
- * reference's own tsqEncode/tsqDecode from oracle/_ref when supplied, else the
- * port above.  Like the reference's workers, decode goes to a private buffer
- * and is then copied (tsq_threads.cpp:590,648), because the reference decoder
- * over-copies past the block end.
+ * CPU baseline driver for bench.py (SURVEY.md 8d protocol): encode then decode
+ * of one buffer on a persistent pthread pool, block b -> thread b % T (the
+ * reference's assignment, tsq_threads.cpp:71), wall clock per phase, one
+ * untimed warm pass and `reps` timed ones (every time is returned: the caller
+ * takes median and best).  `enc`/`dec` are the reference's own
+ * tsqEncode/tsqDecode from oracle/_ref when supplied, else the port above.
+ *
+ *  - threads are pinned, one per allowed CPU in order (pin != 0);
+ *  - every worker first-touches the slots, decode scratch and output pages
+ *    of the blocks it owns, so the pages are local to its NUMA node;
+ *  - shape 0 "idealised": workers write their results in place and that is
+ *    all (decode of the reference's over-copying decoder goes through a
+ *    private buffer and is copied by the worker itself);
+ *    shape 1 "reference-shaped": as the reference's pipeline, ONE writer
+ *    thread takes the finished blocks in block order and copies them to the
+ *    final buffer -- frames into a contiguous container on encode
+ *    (tsq_threads.cpp:226-239), blocks into the output on decode (:648) --
+ *    while the workers run.
  * ---------------------------------------------------------------------- */
 typedef void (*tsqo_enc_fn)(void *ctx, uint8_t *in, uint8_t *out, uint32_t *outsz, uint32_t insz, uint32_t ext);
 typedef void (*tsqo_dec_fn)(uint8_t *in, uint8_t *out, uint32_t *outsz, uint32_t insz, uint32_t ext);
@@ -431,18 +442,39 @@ typedef struct {
     tsqo_enc_fn enc; tsqo_dec_fn dec;
     const uint8_t *in; size_t n; uint32_t ext; size_t nb;
     uint8_t *slots; size_t stride; uint32_t *sizes; uint8_t *back;
-    int nthreads; int phase;            /* 0 encode, 1 decode, 2 quit */
-    pthread_barrier_t go, done;
+    uint8_t *container; uint8_t *stage;            /* shape 1: gathered frames; per-block decode staging */
+    volatile int *done;                            /* shape 1: per-block completion flags */
+    int nthreads; int phase;                       /* 0 encode, 1 decode, 2 quit, 3 first touch */
+    int shape; int pin; int ncpu; int *cpus;
+    pthread_barrier_t go, fin;
 } bench_shared;
 typedef struct { bench_shared *sh; int tid; } bench_arg;
+
+static void pin_to(bench_shared *sh, int slot)
+{
+#ifdef __linux__
+    if (sh->pin && sh->ncpu > 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(sh->cpus[slot % sh->ncpu], &set);
+        (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+    }
+#else
+    (void)sh; (void)slot;
+#endif
+}
 
 static void *bench_worker(void *p)
 {
     bench_arg *a = (bench_arg *)p;
     bench_shared *sh = a->sh;
-    uint16_t *table = (uint16_t *)aligned_alloc(128, TSQO_HASH_ENTRIES * sizeof(uint16_t));
-    uint8_t *scratch = (uint8_t *)malloc(TSQO_BLOCK_SZ + 4096);
-    struct { uint16_t *refhash; } ctx = { table };
+    uint16_t *table;
+    uint8_t *scratch;
+    struct { uint16_t *refhash; } ctx;
+    pin_to(sh, a->tid);
+    table = (uint16_t *)aligned_alloc(128, TSQO_HASH_ENTRIES * sizeof(uint16_t));
+    scratch = (uint8_t *)malloc(TSQO_BLOCK_SZ + 4096);
+    ctx.refhash = table;
     memset(scratch, 0, TSQO_BLOCK_SZ + 4096);
     for (;;) {
         size_t b;
@@ -452,66 +484,133 @@ static void *bench_worker(void *p)
             size_t at = b * TSQO_BLOCK_SZ;
             uint32_t len = (uint32_t)(sh->n - at < TSQO_BLOCK_SZ ? sh->n - at : TSQO_BLOCK_SZ), sz = 0;
             uint8_t *slot = sh->slots + b * sh->stride;
-            if (sh->phase == 0) {
+            if (sh->phase == 3) {                   /* first touch by the owner; canonical zero-filled output */
+                memset(slot, 0, sh->stride);
+                memset(sh->back + at, 0, len);
+                if (sh->stage) memset(sh->stage + b * (size_t)(TSQO_BLOCK_SZ + 4096), 0, TSQO_BLOCK_SZ + 4096);
+            } else if (sh->phase == 0) {
                 if (sh->enc) { memset(table, 0, TSQO_HASH_ENTRIES * sizeof(uint16_t)); sh->enc(&ctx, (uint8_t *)sh->in + at, slot, &sz, len, sh->ext); }
                 else sz = tsqo_encode_block(sh->in + at, len, slot, sh->ext, table);
                 sh->sizes[b] = sz;
+                if (sh->shape) __atomic_store_n(&sh->done[b], 1, __ATOMIC_RELEASE);
             } else {
-                if (sh->dec) { sh->dec(slot, scratch, &sz, sh->sizes[b], sh->ext); memcpy(sh->back + at, scratch, sz); }
-                else { int st; tsqo_decode_block(slot, sh->sizes[b], sh->back + at, sh->ext, &st); }
+                uint8_t *dst = sh->shape ? sh->stage + b * (size_t)(TSQO_BLOCK_SZ + 4096) : (sh->dec ? scratch : sh->back + at);
+                if (sh->dec) sh->dec(slot, dst, &sz, sh->sizes[b], sh->ext);
+                else { int st; tsqo_decode_block(slot, sh->sizes[b], dst, sh->ext, &st); }
+                if (sh->shape) __atomic_store_n(&sh->done[b], 1, __ATOMIC_RELEASE);
+                else if (sh->dec) memcpy(sh->back + at, scratch, len);
             }
         }
-        pthread_barrier_wait(&sh->done);
+        pthread_barrier_wait(&sh->fin);
     }
     free(table); free(scratch);
     return NULL;
 }
 
-#include <time.h>
+/* shape 1: the single ordered writer (compression_write_worker / decompression_write_worker) */
+static void *bench_writer(void *p)
+{
+    bench_shared *sh = (bench_shared *)p;
+    pin_to(sh, sh->nthreads);
+    for (;;) {
+        size_t b, cur = 16;
+        pthread_barrier_wait(&sh->go);
+        if (sh->phase == 2) break;
+        if (sh->phase == 0 || sh->phase == 1) {
+            for (b = 0; b < sh->nb; b++) {
+                size_t at = b * TSQO_BLOCK_SZ;
+                uint32_t len = (uint32_t)(sh->n - at < TSQO_BLOCK_SZ ? sh->n - at : TSQO_BLOCK_SZ);
+                while (!__atomic_load_n(&sh->done[b], __ATOMIC_ACQUIRE)) sched_yield();
+                sh->done[b] = 0;
+                if (sh->phase == 0) {
+                    uint32_t frame = sh->sizes[b] | (sh->ext ? 0x800000u : 0u);
+                    sh->container[cur] = (uint8_t)frame; sh->container[cur + 1] = (uint8_t)(frame >> 8); sh->container[cur + 2] = (uint8_t)(frame >> 16);
+                    memcpy(sh->container + cur + 3, sh->slots + b * sh->stride, sh->sizes[b]);
+                    cur += 3 + sh->sizes[b];
+                } else memcpy(sh->back + at, sh->stage + b * (size_t)(TSQO_BLOCK_SZ + 4096), len);
+            }
+        }
+        pthread_barrier_wait(&sh->fin);
+    }
+    return NULL;
+}
+
 static double wall_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
-/* `in` needs TSQO_HALO readable bytes after in[n-1].  Returns 0 when the round trip is exact. */
-int tsqo_cpubench(void *enc, void *dec, const uint8_t *in, size_t n, uint32_t ext, int threads, int reps,
-                  double *enc_seconds, double *dec_seconds, uint64_t *compressed_bytes)
+/* `in` needs TSQO_HALO readable bytes after in[n-1].  enc_seconds / dec_seconds: `reps` entries each.
+ * Returns 0 when the round trip is exact. */
+int tsqo_cpubench2(void *enc, void *dec, const uint8_t *in, size_t n, uint32_t ext, int threads, int reps, int shape, int pin,
+                   double *enc_seconds, double *dec_seconds, uint64_t *compressed_bytes)
 {
     bench_shared sh;
-    pthread_t *th; bench_arg *args;
-    int t, r, bad;
-    double best_e = 1e30, best_d = 1e30;
+    pthread_t *th, wr;
+    bench_arg *args;
+    int t, r, bad, parties;
     size_t b;
     if (threads < 1) threads = 1;
     memset(&sh, 0, sizeof sh);
     sh.enc = (tsqo_enc_fn)enc; sh.dec = (tsqo_dec_fn)dec; sh.in = in; sh.n = n; sh.ext = ext;
+    sh.shape = shape ? 1 : 0; sh.pin = pin;
     sh.nb = (n + TSQO_BLOCK_SZ - 1) / TSQO_BLOCK_SZ;
     sh.stride = ((size_t)tsqo_bound(TSQO_BLOCK_SZ) + 4096 + 4095) & ~(size_t)4095;
-    sh.slots = (uint8_t *)malloc(sh.nb * sh.stride);
+    sh.slots = (uint8_t *)malloc(sh.nb * sh.stride);            /* untouched: the owners fault their pages in */
     sh.sizes = (uint32_t *)calloc(sh.nb, sizeof(uint32_t));
     sh.back = (uint8_t *)malloc(n + 4096);
+    if (sh.shape) {
+        sh.container = (uint8_t *)malloc(16 + sh.nb * (3 + (size_t)tsqo_bound(TSQO_BLOCK_SZ)));
+        sh.stage = (uint8_t *)malloc(sh.nb * (size_t)(TSQO_BLOCK_SZ + 4096));
+        sh.done = (volatile int *)calloc(sh.nb, sizeof(int));
+        if (sh.container) memset(sh.container, 0, 16 + sh.nb * (3 + (size_t)tsqo_bound(TSQO_BLOCK_SZ)));   /* the writer's pages, touched once */
+    }
     sh.nthreads = threads;
-    memset(sh.slots, 0, sh.nb * sh.stride);       /* canonical zero-filled output; also pre-faults */
-    memset(sh.back, 0, n + 4096);
-    pthread_barrier_init(&sh.go, NULL, (unsigned)threads + 1);
-    pthread_barrier_init(&sh.done, NULL, (unsigned)threads + 1);
+#ifdef __linux__
+    {
+        cpu_set_t set;
+        int c;
+        sh.cpus = (int *)malloc(sizeof(int) * CPU_SETSIZE);
+        if (sched_getaffinity(0, sizeof set, &set) == 0)
+            for (c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &set)) sh.cpus[sh.ncpu++] = c;
+    }
+#endif
+    parties = threads + 1 + sh.shape;
+    pthread_barrier_init(&sh.go, NULL, (unsigned)parties);
+    pthread_barrier_init(&sh.fin, NULL, (unsigned)parties);
     th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
     args = (bench_arg *)malloc(sizeof(bench_arg) * (size_t)threads);
     for (t = 0; t < threads; t++) { args[t].sh = &sh; args[t].tid = t; pthread_create(&th[t], NULL, bench_worker, &args[t]); }
+    if (sh.shape) pthread_create(&wr, NULL, bench_writer, &sh);
+    sh.phase = 3;
+    pthread_barrier_wait(&sh.go); pthread_barrier_wait(&sh.fin);
     for (r = 0; r <= reps; r++) {                 /* r == 0 is the warm pass */
         double t0, t1, t2;
         sh.phase = 0; t0 = wall_now();
-        pthread_barrier_wait(&sh.go); pthread_barrier_wait(&sh.done);
+        pthread_barrier_wait(&sh.go); pthread_barrier_wait(&sh.fin);
         t1 = wall_now(); sh.phase = 1;
-        pthread_barrier_wait(&sh.go); pthread_barrier_wait(&sh.done);
+        pthread_barrier_wait(&sh.go); pthread_barrier_wait(&sh.fin);
         t2 = wall_now();
-        if (r > 0) { if (t1 - t0 < best_e) best_e = t1 - t0; if (t2 - t1 < best_d) best_d = t2 - t1; }
+        if (r > 0) { if (enc_seconds) enc_seconds[r - 1] = t1 - t0; if (dec_seconds) dec_seconds[r - 1] = t2 - t1; }
     }
     sh.phase = 2;
     pthread_barrier_wait(&sh.go);
     for (t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    if (sh.shape) pthread_join(wr, NULL);
     bad = memcmp(sh.back, in, n) != 0;
     if (compressed_bytes) { uint64_t c = 16; for (b = 0; b < sh.nb; b++) c += 3 + sh.sizes[b]; *compressed_bytes = c; }
-    if (enc_seconds) *enc_seconds = best_e;
-    if (dec_seconds) *dec_seconds = best_d;
-    pthread_barrier_destroy(&sh.go); pthread_barrier_destroy(&sh.done);
-    free(th); free(args); free(sh.slots); free(sh.sizes); free(sh.back);
+    pthread_barrier_destroy(&sh.go); pthread_barrier_destroy(&sh.fin);
+    free(th); free(args); free(sh.slots); free(sh.sizes); free(sh.back); free(sh.container); free(sh.stage); free((void *)sh.done); free(sh.cpus);
+    return bad;
+}
+
+/* the first form of the driver: idealised shape, unpinned, best of `reps` */
+int tsqo_cpubench(void *enc, void *dec, const uint8_t *in, size_t n, uint32_t ext, int threads, int reps,
+                  double *enc_seconds, double *dec_seconds, uint64_t *compressed_bytes)
+{
+    double *te = (double *)malloc(sizeof(double) * (size_t)(reps > 0 ? reps : 1)), *td = (double *)malloc(sizeof(double) * (size_t)(reps > 0 ? reps : 1));
+    double be = 1e30, bd = 1e30;
+    int r, bad = tsqo_cpubench2(enc, dec, in, n, ext, threads, reps, 0, 0, te, td, compressed_bytes);
+    for (r = 0; r < reps; r++) { if (te[r] < be) be = te[r]; if (td[r] < bd) bd = td[r]; }
+    if (enc_seconds) *enc_seconds = be;
+    if (dec_seconds) *dec_seconds = bd;
+    free(te); free(td);
     return bad;
 }

@@ -74,6 +74,8 @@ size_t tsqo_decompress(const uint8_t *in, size_t n, uint8_t *out, size_t out_cap
 /* CPU baseline for bench.py: block-parallel encode+decode on `threads` pthreads, best of `reps`
  * warm passes.  enc/dec: addresses of the reference's tsqEncode/tsqDecode (oracle/_ref) or NULL
  * for the port.  Returns 0 when the round trip reproduced the input. */
+int tsqo_cpubench2(void *enc, void *dec, const uint8_t *in, size_t n, uint32_t ext, int threads, int reps, int shape, int pin,
+                   double *enc_seconds, double *dec_seconds, uint64_t *compressed_bytes);
 int tsqo_cpubench(void *enc, void *dec, const uint8_t *in, size_t n, uint32_t ext, int threads, int reps,
                   double *enc_seconds, double *dec_seconds, uint64_t *compressed_bytes);
 

@@ -56,3 +56,24 @@ def test_fails_loudly_without_gpu():
     assert tsq.tsq_decode(b"\x05\x00\x00\xff\x40hello", 0) == b""
     with pytest.raises(tsq.TsqError):
         tsq.tsq_compress_mt(b"x" * 100, False)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/test/test.cpp"), reason="no reference tree here (build container only)")
+@pytest.mark.parametrize("source", ["test/test.cpp", "sample/main.cpp"])
+def test_reference_programs_link_against_this_library(tmp_path, source):
+    """Drop-in at the ABI: the reference's own test program and sample program, compiled from where they lie against
+    the reference's own headers, LINK against libturbosqueeze_amd.so with no unresolved symbol.  (Nothing is copied;
+    -D_MSC_VER -mbmi selects platform.h's second branch because this image has no <stdbit.h>, as in oracle/Makefile.
+    The programs are not run here: there is no GPU in the build container.)"""
+    obj, exe = tmp_path / "prog.o", tmp_path / "prog"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-D_MSC_VER=1900", "-mbmi", "-c", os.path.join("/root/reference", source), "-o", str(obj)],
+                   check=True, capture_output=True, timeout=300)
+    r = subprocess.run(["g++", "-o", str(exe), str(obj), "-L" + os.path.dirname(tsq.lib_path()), "-lturbosqueeze_amd",
+                        "-L/opt/rocm/lib", "-lamdhip64", "-lpthread", "-Wl,--no-undefined"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    undefined = subprocess.run(["nm", "-u", str(exe)], capture_output=True, text=True).stdout
+    wanted = {l.split()[-1] for l in undefined.splitlines() if " tsq" in l}
+    assert wanted, "the program does not reference the library at all?"
+    exported = subprocess.run(["nm", "-D", "--defined-only", tsq.lib_path()], capture_output=True, text=True).stdout
+    have = {l.split()[-1] for l in exported.splitlines()}
+    assert wanted <= have, sorted(wanted - have)

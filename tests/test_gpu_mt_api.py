@@ -55,6 +55,96 @@ def test_compress_mt_multibatch(tsq, oracle):
         del os.environ["TSQ_AMD_BATCH_BLOCKS"]
 
 
+def test_multi_device_scheduler_path(tsq, oracle, monkeypatch):
+    """The scheduler's spread over several devices (TSQ_AMD_DEVICES), exercised on one GPU by listing it twice: a job
+    that would fit one batch is cut into one slice of consecutive blocks per listed device, each slice with its
+    look-ahead, gathered on the host in block order.  Also with small batches, so that several batches per device
+    are in flight."""
+    host = tsq.synth.text(7 * (1 << 22) + 31337, seed=32)
+    for edge in (3, 4, 6):                                  # matches across every possible slice boundary
+        host[edge * (1 << 22) - 30:edge * (1 << 22) + 30] = np.resize(np.frombuffer(b"slice-edge ", dtype=np.uint8), 60)
+    data = host.tobytes()
+    monkeypatch.setenv("TSQ_AMD_DEVICES", "0,0")
+    for batch in (None, "3"):
+        if batch:
+            monkeypatch.setenv("TSQ_AMD_BATCH_BLOCKS", batch)
+        for ext in (False, True):
+            blob = tsq.tsq_compress_mt(data, ext)
+            assert blob == oracle.compress(host, int(ext), threads=4), (batch, ext)
+            assert tsq.tsq_decompress_mt(blob) == data, (batch, ext)
+
+
+def test_progress_fires_once_per_block_in_order(tsq):
+    """tsq_threads.cpp:248-254,654-655: progress_cb once per written block, fractions k / n_blocks in order."""
+    L = tsq.lib()
+    nb = 21
+    data = tsq.synth.text(nb * (1 << 22) - 1000, seed=33).tobytes()
+    src = C.create_string_buffer(data, len(data))
+    seen = []
+    pcb = tsq.api.PROGRESS_FN(lambda jobid, frac, user: seen.append((jobid, frac)))
+    done = []
+    dcb = tsq.api.DONE_FN(lambda jobid, ok, user: done.append((jobid, ok, len(seen))))
+    cctx = L.tsqAllocateContextCompression_MT(False)
+    out, sz = C.c_void_p(), C.c_size_t(0)
+    jid = L.tsqa_compress_async_cb(cctx, src, len(data), False, C.byref(out), C.byref(sz), False, False, 0,
+                                   C.cast(dcb, C.c_void_p), C.cast(pcb, C.c_void_p), None)
+    L.tsqDeallocateContextCompression_MT(cctx)
+    assert done == [(jid, True, nb)]                         # every progress call came before the completion call
+    assert [f for _, f in seen] == [(k + 1) / nb for k in range(nb)]
+    blob = C.string_at(out, sz.value)
+    seen.clear(); done.clear()
+    dctx = L.tsqAllocateContextDecompression_MT(False)
+    src2 = C.create_string_buffer(blob, len(blob))
+    out2, sz2 = C.c_void_p(), C.c_size_t(0)
+    jid2 = L.tsqa_decompress_async_cb(dctx, src2, len(blob), False, C.byref(out2), C.byref(sz2), False,
+                                      C.cast(dcb, C.c_void_p), C.cast(pcb, C.c_void_p), None)
+    L.tsqDeallocateContextDecompression_MT(dctx)
+    assert done == [(jid2, True, nb)]
+    assert [f for _, f in seen] == [(k + 1) / nb for k in range(nb)]
+    assert C.string_at(out2, sz2.value) == data
+    tsq.api._libc.free(out); tsq.api._libc.free(out2)
+
+
+def test_st_file_api(tsq, oracle, tmp_path):
+    """tsqCompress(FILE*, FILE*) / tsqDecompress(FILE*, FILE*) (turbosqueeze.cpp:48-95,98-147): file -> .tsq container ->
+    file, streams supplied and kept open by the caller, `level` ignored, silent return on a bad container."""
+    L = tsq.lib()
+    libc = tsq.api._libc
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    libc.ftell.restype = C.c_long
+    libc.ftell.argtypes = [C.c_void_p]
+    host = tsq.synth.text(2 * (1 << 22) + 4242, seed=34)
+    src, mid, dst = tmp_path / "in.bin", tmp_path / "out.tsq", tmp_path / "back.bin"
+    src.write_bytes(host.tobytes())
+    for ext, level in ((False, 0), (True, 3)):
+        fin, fout = libc.fopen(str(src).encode(), b"rb"), libc.fopen(str(mid).encode(), b"wb")
+        L.tsqCompress(fin, fout, ext, level)
+        assert libc.ftell(fout) > 16                         # the caller's stream is still open and positioned after the data
+        libc.fclose(fin); libc.fclose(fout)
+        assert mid.read_bytes() == oracle.compress(host, int(ext), threads=2)
+        fin, fout = libc.fopen(str(mid).encode(), b"rb"), libc.fopen(str(dst).encode(), b"wb")
+        L.tsqDecompress(fin, fout)
+        libc.fclose(fin); libc.fclose(fout)
+        assert dst.read_bytes() == host.tobytes()
+    # bad magic / short header: nothing written, no crash (turbosqueeze.cpp:106-117)
+    for bad in (b"NOPE" + bytes(60), b"TSQ1" + bytes(5)):
+        mid.write_bytes(bad)
+        fin, fout = libc.fopen(str(mid).encode(), b"rb"), libc.fopen(str(dst).encode(), b"wb")
+        L.tsqDecompress(fin, fout)
+        libc.fclose(fin); libc.fclose(fout)
+        assert dst.read_bytes() == b""
+
+
+def test_hostile_header_is_rejected_before_allocation(tsq):
+    """A 22-byte container that claims 25 600 blocks / 100 GiB must fail at once instead of committing memory."""
+    blob = b"TSQ1" + (25600).to_bytes(4, "little") + (100 << 30).to_bytes(8, "little") + b"\x03\x00\x00\x01\x00\x00"
+    assert tsq.tsq_decompress_mt(blob) is None
+    blob = b"TSQ1" + (1).to_bytes(4, "little") + (4 << 20).to_bytes(8, "little") + b"\x03\x00\x00\x00\x00\x40"
+    assert tsq.tsq_decompress_mt(blob) is None              # 4 MiB claimed from a 3-byte stream
+
+
 def test_bad_arguments(tsq):                              # tsq_threads.cpp:415-418
     L = tsq.lib()
     c = L.tsqAllocateContextCompression_MT(False)

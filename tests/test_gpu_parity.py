@@ -158,65 +158,99 @@ def test_enwik8_sized_bit_exact(codec, oracle, tsq):
     assert torch.equal(codec.decompress(blob), dev)
 
 
-def test_enwik9_sized_roundtrip_properties(codec, oracle, tsq):
-    """BASELINE.json config 3 at full size: round trip identity, container structure, and a sampled
-    block compared with the oracle (size-independent properties; full compare is config 2)."""
+def frames_of(raw, nb):
+    at, frames = 16, []
+    for _ in range(nb):
+        ln = int(raw[at]) | int(raw[at + 1]) << 8 | (int(raw[at + 2]) & 0x7F) << 16
+        frames.append((at + 3, ln, int(raw[at + 2]) >> 7))
+        at += 3 + ln
+    assert at == raw.size
+    return frames
+
+
+def assert_same_container(raw, want, nb):
+    """Byte compare of two containers; on a mismatch, name the first block that differs."""
+    want = np.frombuffer(want, dtype=np.uint8)
+    if raw.size == want.size and np.array_equal(raw, want):
+        return
+    fa, fb = frames_of(raw, nb), frames_of(want, nb)
+    for b, (x, y) in enumerate(zip(fa, fb)):
+        assert x[1] == y[1], f"block {b}: stream sizes differ ({x[1]} vs {y[1]})"
+        assert np.array_equal(raw[x[0]:x[0] + x[1]], want[y[0]:y[0] + y[1]]), f"block {b}: stream bytes differ"
+    raise AssertionError("containers differ outside the frames")
+
+
+@pytest.mark.parametrize("ext", [0, 1])
+def test_enwik9_sized_full_compare(codec, oracle, tsq, ext):
+    """BASELINE.json config 3 at full size (10^9 B, 239 blocks, both levels): the WHOLE container byte for byte
+    against the oracle, and the round trip."""
     import torch
     n = 1_000_000_000
     host = tsq.synth.text(n, seed=9)
     dev = to_dev(host)
-    blob = codec.compress(dev, 0)
-    head = to_bytes(blob[:16])
-    assert head[:4] == b"TSQ1" and int.from_bytes(head[4:8], "little") == 239
-    assert int.from_bytes(head[8:16], "little") == n
-    ratio = blob.numel() / n
-    assert 0.60 < ratio < 0.64, ratio
+    blob = codec.compress(dev, ext)
+    raw = blob.cpu().numpy()
+    assert bytes(raw[:4]) == b"TSQ1" and int.from_bytes(bytes(raw[4:8]), "little") == 239
+    assert int.from_bytes(bytes(raw[8:16]), "little") == n
+    assert 0.60 < raw.size / n < 0.64
+    want = oracle.compress(host, ext, threads=os.cpu_count() or 8)
+    assert_same_container(raw, want, 239)
+    del want
     back = codec.decompress(blob)
     assert torch.equal(back, dev)
-    # walk the frames on the host and check three blocks against the oracle
-    raw = blob.cpu().numpy()
-    at, frames = 16, []
-    for _ in range(239):
-        ln = int(raw[at]) | int(raw[at + 1]) << 8 | (int(raw[at + 2]) & 0x7F) << 16
-        frames.append((at + 3, ln))
-        at += 3 + ln
-    assert at == raw.size
-    for b in (0, 117, 238):
-        lo = b << 22
-        hi = min(n, lo + (1 << 22))
-        want = oracle.encode_block(host[lo:hi], 0, halo=bytes(host[hi:hi + 128]))
-        s, ln = frames[b]
-        assert bytes(raw[s:s + ln]) == want, b
 
 
-def test_more_blocks_than_cus_lean_layouts(codec, oracle, tsq):
-    """More blocks than CUs (1.25 GiB = 320 blocks, a 10 GiB / 8 GPU shard of BASELINE.json config 5): the default kernels
-    switch to their lean layouts (two blocks per CU).  Round trip identity, with extensions, on the 50 % mix, and sampled
-    blocks against the oracle."""
+@pytest.mark.parametrize("kind", ["text", "mix", "zeros", "random"])
+def test_more_blocks_than_cus_lean_layouts_full_compare(codec, oracle, tsq, kind):
+    """More blocks than CUs (1.25 GiB = 321 blocks, a 10 GiB / 8 GPU shard of BASELINE.json config 5): the default
+    kernels switch to their lean layouts (two blocks per CU).  With extensions, on each config-5 input: the WHOLE
+    container against the oracle, and the round trip."""
     import torch
     n = 5 * (1 << 28) + 12345
     nb = (n + (1 << 22) - 1) >> 22
-    host = tsq.synth.mix(n, seed=13)
+    assert nb > 256
+    host = {"text": lambda: tsq.synth.text(n, seed=14), "mix": lambda: tsq.synth.mix(n, seed=13),
+            "zeros": lambda: np.zeros(n, dtype=np.uint8), "random": lambda: tsq.synth.random_bytes(n, 15)}[kind]()
     dev = to_dev(host)
     blob = codec.compress(dev, 1)
-    back = codec.decompress(blob)
-    assert torch.equal(back, dev)
-    del back
     raw = blob.cpu().numpy()
     assert int.from_bytes(bytes(raw[4:8]), "little") == nb
-    at, frames = 16, []
-    for _ in range(nb):
-        ln = int(raw[at]) | int(raw[at + 1]) << 8 | (int(raw[at + 2]) & 0x7F) << 16
-        assert int(raw[at + 2]) >> 7 == 1                      # the extension flag of the frame
-        frames.append((at + 3, ln))
-        at += 3 + ln
-    assert at == raw.size
-    for b in (0, 200, nb - 1):
-        lo = b << 22
-        hi = min(n, lo + (1 << 22))
-        want = oracle.encode_block(host[lo:hi], 1, halo=bytes(host[hi:hi + 128]))
-        s0, ln = frames[b]
-        assert bytes(raw[s0:s0 + ln]) == want, b
+    assert all(e == 1 for _, _, e in frames_of(raw, nb))           # the extension flag of every frame
+    want = oracle.compress(host, 1, threads=os.cpu_count() or 8)
+    assert_same_container(raw, want, nb)
+    del want, raw
+    back = codec.decompress(blob)
+    assert torch.equal(back, dev)
+
+
+def test_config1_single_256k_block(tsq, oracle):
+    """BASELINE.json config 1: one 262 144-byte block of enwik-shaped text through tsqEncode / tsqDecode, --no-ext."""
+    data = tsq.synth.text(262144, seed=1).tobytes()
+    for ext in (0, 1):
+        stream = tsq.tsq_encode(data, ext)
+        assert stream == oracle.encode_block(data, ext)
+        assert int.from_bytes(stream[:3], "little") == 262144
+        assert tsq.tsq_decode(stream, ext) == data
+
+
+def test_tsqencode_lookahead_matches_reference_contract(tsq, oracle):
+    """The reference's encoder reads past inputBlock[inputSize-1] (tsq_encode.cpp:74,126) and its scheduler relies
+    on it (tsq_threads.cpp:109).  tsqEncode here does the same: looping over the blocks of one contiguous buffer gives
+    the container's streams (block k's look-ahead is block k+1), and a block followed by zeros gives the canonical
+    last-block stream."""
+    n = (1 << 22) + 70000
+    host = tsq.synth.text(n, seed=77)
+    host[(1 << 22) - 20:(1 << 22) + 20] = np.resize(np.frombuffer(b"edge", dtype=np.uint8), 40)   # a match across the block edge
+    first, rest = host[:1 << 22].tobytes(), host[1 << 22:].tobytes()
+    for ext in (0, 1):
+        with_next = tsq.tsq_encode(first, ext, halo=rest[:128])
+        alone = tsq.tsq_encode(first, ext)
+        assert with_next == oracle.encode_block(first, ext, halo=rest[:128])
+        assert alone == oracle.encode_block(first, ext)
+        assert with_next != alone                                   # the look-ahead is really used
+        blob = oracle.compress(host, ext, threads=2)
+        ln = int.from_bytes(blob[16:19], "little") & 0x7FFFFF
+        assert blob[19:19 + ln] == with_next
 
 
 def test_container_errors(codec, tsq, oracle):
@@ -268,15 +302,73 @@ def test_corrupted_containers_agree_with_oracle(codec, tsq, oracle):
 
 
 def test_all_kernel_variants_agree(tsq, oracle):
-    """Every encoder / decoder generation kept for A/B produces the oracle's bytes."""
-    c = tsq.DeviceCodec(0)
+    """The product kernels (staged encoder / ring decoder, their lean layouts, the serial baselines) and, from the A/B
+    library (make ab), every superseded generation kept for measurements produce the oracle's bytes."""
     host = np.concatenate([tsq.synth.text(6_000_000, seed=21), tsq.synth.mix(3_000_000, seed=22)])
     dev = to_dev(host)
+    want = {ext: oracle.compress(host, ext, threads=4) for ext in (0, 1)}
+    for ab, variants in ((False, ((0, 0), (1, 1), (6, 6), (7, 7))), (True, ((0, 0), (2, 2), (3, 0), (4, 0), (5, 0)))):
+        assert os.path.exists(tsq.lib_path(ab)), "run __graft_entry__.build() first"
+        c = tsq.DeviceCodec(0, ab=ab)
+        for ext in (0, 1):
+            for enc_variant, dec_variant in variants:
+                c.set_variant(enc_variant, dec_variant)
+                blob = c.compress(dev, ext)
+                assert to_bytes(blob) == want[ext], (ab, enc_variant, ext)
+                assert to_bytes(c.decompress(blob)) == host.tobytes(), (ab, dec_variant, ext)
+        c.close()
+    # the product library does not carry the superseded kernels
+    c = tsq.DeviceCodec(0)
+    c.set_variant(3, 2)
+    with pytest.raises(tsq.TsqError):
+        c.compress(dev, 0)
+    c.close()
+
+
+def test_sharded_blocks_api(tsq, oracle):
+    """tsqa_encode_blocks_async / tsqa_decode_blocks_async / tsqa_frames_{to,from}_host_async through ShardedCodec:
+    one job dealt over 3 'ranks' (three contexts on this GPU, one after the other), frames gathered in ONE host
+    container -> the oracle's container; every rank decodes its own frames back."""
+    import torch
+    from turbosqueeze_amd import sharding
+    n = 7 * (1 << 22) + 4567
+    host = tsq.synth.text(n, seed=91)
+    host[3 * (1 << 22) - 25:3 * (1 << 22) + 25] = np.resize(np.frombuffer(b"shard-edge", dtype=np.uint8), 50)
+    world = 3
     for ext in (0, 1):
         want = oracle.compress(host, ext, threads=4)
-        for enc_variant, dec_variant in ((0, 0), (1, 1), (2, 2), (3, 0), (4, 0), (5, 0), (6, 6)):
-            c.set_variant(enc_variant, dec_variant)
-            blob = c.compress(dev, ext)
-            assert to_bytes(blob) == want, (enc_variant, ext)
-            assert to_bytes(c.decompress(blob)) == host.tobytes(), (dec_variant, ext)
-    c.close()
+        hc = sharding.HostContainer("tsq_test_shard_%d_%d" % (os.getpid(), ext), tsq.container_bound(n), create=True)
+        hc.register()
+        try:
+            codecs, coders, lays = [], [], []
+            for r in range(world):
+                lay = sharding.ShardLayout(n, r, world)
+                c = tsq.DeviceCodec(0)
+                sc = sharding.ShardedCodec(lay, sharding.DeviceBlocks(c), hc, ext)
+                # world > 1 without torch.distributed: hand every coder the full size table by running them in turn
+                codecs.append(c); coders.append(sc); lays.append(lay)
+            # encode every shard, collect sizes (what the all-gather does), then place the frames
+            all_sizes = np.zeros(lays[0].nb, dtype=np.uint32)
+            shards = []
+            for r in range(world):
+                d = to_dev(lays[r].pack_input(host))
+                shards.append(d)
+                coders[r].blocks.encode(d, lays[r].n_local, lays[r].stride, lays[r].last_len, ext)
+                coders[r].blocks.sync()
+                all_sizes[np.asarray(lays[r].blocks)] = coders[r].blocks.sizes_tensor().cpu().numpy().astype(np.uint32)[:lays[r].n_local]
+            frame_at, total = sharding.frame_offsets(all_sizes)
+            hc.array[:16] = np.frombuffer(b"TSQ1" + lays[0].nb.to_bytes(4, "little") + n.to_bytes(8, "little"), dtype=np.uint8)
+            for r in range(world):
+                own = np.asarray(lays[r].blocks)
+                coders[r].blocks.frames_to_host(np.ascontiguousarray(all_sizes[own]), np.ascontiguousarray(frame_at[own]), ext, hc)
+                coders[r].blocks.sync()
+            assert total == len(want)
+            assert bytes(hc.array[:total]) == want
+            for r in range(world):
+                back = torch.empty(lays[r].shard_bytes, dtype=torch.uint8, device="cuda")
+                assert coders[r].decompress(total, back) == n
+                assert np.array_equal(back.cpu().numpy(), lays[r].expected_output(host))
+            for c in codecs:
+                c.close()
+        finally:
+            hc.close()

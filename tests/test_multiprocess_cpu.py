@@ -49,6 +49,64 @@ WORKER = textwrap.dedent('''
     if rank == 0:
         back = b"".join(merged[b][1] for b in range(nb))
         assert back == host.tobytes()
+
+    # ---- the one-process-per-GPU product path (ShardLayout + HostContainer + ShardedCodec: the all-gather of sizes,
+    #      frame offsets, header, frames DMA'd to their place, frame walk, decode of owned frames) with the per-block
+    #      device work replaced by the oracle on numpy arrays -- the host logic is the code bench.py --gpus N runs
+    class OracleBlocks:
+        def alloc(self, n_local):
+            self.slots = np.zeros(max(n_local, 1) * sharding.OUTPUT_SZ, dtype=np.uint8)
+            self.sizes = torch.zeros(max(n_local, 1), dtype=torch.int32)
+        def encode(self, d_in, n_local, stride, last_len, ext):
+            for k in range(n_local):
+                ln = last_len if k == n_local - 1 else sharding.BLOCK_SZ
+                blk = d_in[k * stride:k * stride + ln]
+                stream = orc.encode_block(blk, ext, halo=bytes(d_in[k * stride + ln:k * stride + ln + 128]))
+                self.slots[k * sharding.OUTPUT_SZ:k * sharding.OUTPUT_SZ + len(stream)] = np.frombuffer(stream, dtype=np.uint8)
+                self.sizes[k] = len(stream)
+        def sizes_tensor(self):
+            return self.sizes
+        def frames_to_host(self, sizes, frame_at, ext, hostc):
+            for k in range(len(sizes)):
+                frame = int(sizes[k]) | (0x800000 if ext else 0)
+                at = int(frame_at[k])
+                hostc.array[at:at + 3] = np.frombuffer(frame.to_bytes(3, "little"), dtype=np.uint8)
+                hostc.array[at + 3:at + 3 + int(sizes[k])] = self.slots[k * sharding.OUTPUT_SZ:k * sharding.OUTPUT_SZ + int(sizes[k])]
+        def frames_from_host(self, hostc, frame_at, sizes):
+            for k in range(len(sizes)):
+                at = int(frame_at[k]) + 3
+                self.slots[k * sharding.OUTPUT_SZ:k * sharding.OUTPUT_SZ + int(sizes[k])] = hostc.array[at:at + int(sizes[k])]
+        def decode(self, fr, n_local, d_out):
+            for k in range(n_local):
+                s0, ln = int(fr["stream_at"][k]), int(fr["stream_len"][k])
+                data, st = orc.decode_block(bytes(self.slots[s0:s0 + ln]), int(fr["ext"][k]))
+                assert st == 0 and len(data) == int(fr["out_len"][k])
+                o = int(fr["out_at"][k])
+                d_out[o:o + len(data)] = np.frombuffer(data, dtype=np.uint8)
+        def sync(self):
+            pass
+
+    for ext in (0, 1):
+        lay = sharding.ShardLayout(n, rank, world)
+        assert sorted(lay.blocks) == sharding.rank_blocks(nb, rank, world) and lay.max_blocks == 2
+        name = "tsq_test_gloo_%s_%d" % (os.environ.get("MASTER_PORT", "0"), ext)
+        if rank == 0:
+            hc = sharding.HostContainer(name, 16 + nb * (3 + sharding.OUTPUT_SZ), create=True)
+        dist.barrier()
+        if rank != 0:
+            hc = sharding.HostContainer(name, 16 + nb * (3 + sharding.OUTPUT_SZ), create=False)
+        sc = sharding.ShardedCodec(lay, OracleBlocks(), hc, ext)
+        shard = lay.pack_input(host)
+        size = sc.compress(shard)
+        dist.barrier()                                   # every rank's frames are in place
+        want = orc.compress(host, ext, threads=2)
+        assert size == len(want)
+        assert bytes(hc.array[:size]) == want, "host-gathered container differs from the single-process one"
+        back = np.zeros(lay.shard_bytes, dtype=np.uint8)
+        assert sc.decompress(size, back) == n
+        assert np.array_equal(back, lay.expected_output(host))
+        dist.barrier()
+        hc.close()
     # ---- bench.py timing harness: K steps between barriers, max over ranks, whole-job aggregate
     calls = []
     def step():
@@ -56,7 +114,7 @@ WORKER = textwrap.dedent('''
     dt = bench.timed_steps(step, steps=3, warmup=1, world=world, device_sync=lambda: None, reduce_device=None)
     assert len(calls) == 4
     assert 0.11 < dt < 0.5, dt                      # the slower rank (2 x 0.02 x 3) sets the time on BOTH ranks
-    value = bench.aggregate_value(world, 10**9, dt, 3)
+    value = bench.aggregate_value(10**9, dt, 3)
     if rank == 0:
         print(json.dumps({{"ok": True, "dt": dt, "value": value}}))
     dist.destroy_process_group()

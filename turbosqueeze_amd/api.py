@@ -26,28 +26,29 @@ class TsqError(RuntimeError):
         super().__init__(f"turbosqueeze_amd error {code} ({ERRORS.get(code, '?')}) {detail}".strip())
 
 
-def lib_path() -> str:
-    return os.path.join(HERE, "libturbosqueeze_amd.so")
+def lib_path(ab: bool = False) -> str:
+    """The product library, or (ab=True) the A/B library that also carries the superseded kernel
+    generations (variants 2-5; `make -C turbosqueeze_amd/csrc ab`)."""
+    return os.path.join(HERE, "libturbosqueeze_amd_ab.so" if ab else "libturbosqueeze_amd.so")
 
 
 def build_native(force: bool = False) -> None:
     """Compile every HIP source for gfx950 into turbosqueeze_amd/*.so (in-tree)."""
     csrc = os.path.join(HERE, "csrc")
-    args = ["make", "-C", csrc, "all"]
+    args = ["make", "-C", csrc, "all", "ab"]
     if force:
         subprocess.check_call(["make", "-C", csrc, "clean"], stdout=subprocess.DEVNULL)
     subprocess.check_call(args, stdout=subprocess.DEVNULL)
 
 
-_lib = None
+_libs = {}
 
 
-def lib() -> C.CDLL:
+def lib(ab: bool = False) -> C.CDLL:
     """Load the native library.  Fails loudly when it is missing: there is no other path."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = lib_path()
+    if ab in _libs:
+        return _libs[ab]
+    path = lib_path(ab)
     if not os.path.exists(path):
         raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950); turbosqueeze_amd has no CPU fallback")
@@ -101,7 +102,23 @@ def lib() -> C.CDLL:
     L.tsqa_compress_async_cb.argtypes = [vp, vp, C.c_size_t, C.c_bool, u8pp, szp, C.c_bool, C.c_bool, C.c_uint32, vp, vp, vp]
     L.tsqa_decompress_async_cb.restype = C.c_uint32
     L.tsqa_decompress_async_cb.argtypes = [vp, vp, C.c_size_t, C.c_bool, u8pp, szp, C.c_bool, vp, vp, vp]
-    _lib = L
+    L.tsqa_profile_read_calls.restype = C.c_int
+    L.tsqa_profile_read_calls.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+    L.tsqa_encode_blocks_async.restype = C.c_int
+    L.tsqa_encode_blocks_async.argtypes = [vp, vp, C.c_uint32, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
+    L.tsqa_decode_blocks_async.restype = C.c_int
+    L.tsqa_decode_blocks_async.argtypes = [vp, vp, vp, C.c_uint32, vp, vp, vp]
+    L.tsqa_frames_to_host_async.restype = C.c_int
+    L.tsqa_frames_to_host_async.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp]
+    L.tsqa_frames_from_host_async.restype = C.c_int
+    L.tsqa_frames_from_host_async.argtypes = [vp, vp, vp, vp, C.c_uint32, vp, vp]
+    L.tsqa_measure_copy.restype = C.c_int
+    L.tsqa_measure_copy.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.tsqCompress.restype = None
+    L.tsqCompress.argtypes = [vp, vp, C.c_bool, C.c_uint32]
+    L.tsqDecompress.restype = None
+    L.tsqDecompress.argtypes = [vp, vp]
+    _libs[ab] = L
     return L
 
 
@@ -118,12 +135,12 @@ def container_bound(n: int) -> int:
 class DeviceCodec:
     """Device-resident compress/decompress over torch uint8 CUDA tensors (tsqa_* C ABI)."""
 
-    def __init__(self, device: int = -1):
+    def __init__(self, device: int = -1, ab: bool = False):
         import torch
         if not torch.cuda.is_available():
             raise TsqError(1, "torch sees no GPU")
         self.torch = torch
-        self.L = lib()
+        self.L = lib(ab)
         self.h = C.c_void_p()
         if device < 0:
             device = torch.cuda.current_device()
@@ -160,8 +177,51 @@ class DeviceCodec:
         self.L.tsqa_profile_read(self.h, C.byref(em), C.byref(en), C.byref(dm), C.byref(dn))
         return em.value, en.value, dm.value, dn.value
 
+    def profile_read_calls(self):
+        """-> (compress_ms_sum, calls, decompress_ms_sum, calls): whole calls (encode + pack; frame walk + decode)."""
+        em, dm, en, dn = C.c_double(0), C.c_double(0), C.c_uint32(0), C.c_uint32(0)
+        self.L.tsqa_profile_read_calls(self.h, C.byref(em), C.byref(en), C.byref(dm), C.byref(dn))
+        return em.value, en.value, dm.value, dn.value
+
+    def measure_copy(self, nbytes: int = 1 << 30, reps: int = 7):
+        """-> (best, median) GB/s of a plain device copy kernel, bytes read + written."""
+        best, med = C.c_double(0), C.c_double(0)
+        rc = self.L.tsqa_measure_copy(self.h, nbytes, reps, C.byref(best), C.byref(med))
+        if rc:
+            raise self._err(rc)
+        return best.value, med.value
+
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- sharded operation: this device owns some of a job's blocks (tsqa_*_blocks_async) ----
+    def encode_blocks_async(self, d_in, n_blocks: int, stride: int, last_len: int, ext: int, d_slots, d_sizes):
+        rc = self.L.tsqa_encode_blocks_async(self.h, d_in.data_ptr(), n_blocks, stride, last_len, int(ext), d_slots.data_ptr(),
+                                             d_sizes.data_ptr(), self._status.data_ptr(), self._stream())
+        if rc:
+            raise self._err(rc)
+
+    def decode_blocks_async(self, d_streams, d_frames, n_blocks: int, d_out):
+        rc = self.L.tsqa_decode_blocks_async(self.h, d_streams.data_ptr(), d_frames.data_ptr(), n_blocks, d_out.data_ptr(),
+                                             self._status.data_ptr(), self._stream())
+        if rc:
+            raise self._err(rc)
+
+    def frames_to_host_async(self, d_slots, sizes, frame_at, ext: int, host_ptr: int):
+        """sizes (uint32) / frame_at (uint64): contiguous numpy arrays, one entry per owned block."""
+        rc = self.L.tsqa_frames_to_host_async(self.h, d_slots.data_ptr(), sizes.ctypes.data, frame_at.ctypes.data, len(sizes), int(ext),
+                                              host_ptr, self._stream())
+        if rc:
+            raise self._err(rc)
+
+    def frames_from_host_async(self, host_ptr: int, frame_at, sizes, d_streams):
+        rc = self.L.tsqa_frames_from_host_async(self.h, host_ptr, frame_at.ctypes.data, sizes.ctypes.data, len(sizes), d_streams.data_ptr(),
+                                                self._stream())
+        if rc:
+            raise self._err(rc)
+
+    def status(self) -> int:
+        return int(self._status.item())
 
     def compress(self, src, ext: int, out=None):
         """src: uint8 CUDA tensor.  Returns a uint8 CUDA tensor view holding the .tsq container."""
@@ -206,11 +266,13 @@ class DeviceCodec:
 # The reference's API over host bytes
 # ---------------------------------------------------------------------------
 
-def tsq_encode(data: bytes, ext: int) -> bytes:
-    """tsqEncode (turbosqueeze.h:657): one block (<= 4 MiB) -> block stream."""
+def tsq_encode(data: bytes, ext: int, halo: bytes = b"") -> bytes:
+    """tsqEncode (turbosqueeze.h:657): one block (<= 4 MiB) -> block stream.  Like the reference, the
+    encoder looks a few bytes past the block (tsq_encode.cpp:74,126): `halo` is what follows the block
+    in the caller's buffer (the next block's first bytes); zeros otherwise (canonical conditions)."""
     L = lib()
     n = len(data)
-    src = C.create_string_buffer(bytes(data), n)
+    src = C.create_string_buffer(bytes(data) + bytes(halo)[:128].ljust(128, b"\0"), n + 128)
     dst = C.create_string_buffer(OUTPUT_SZ)
     sz = C.c_uint32(0)
     ctx = L.tsqAllocateContext()

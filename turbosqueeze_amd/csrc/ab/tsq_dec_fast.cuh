@@ -1,4 +1,4 @@
-// tsq_dec_fast.cuh -- wave-parallel block decoder for gfx950 (kernel variant 0).
+// tsq_dec_fast.cuh -- wave-parallel block decoder for gfx950 (A/B variant 2: superseded, not in the product library).
 //
 // What tsq_decode.cpp:42-315 does with one dependent load per symbol (the position of every
 // size byte depends on all lengths before it) is restated as data-parallel phases over one
@@ -26,7 +26,8 @@
 // nothing), which also makes the pointer graph acyclic.  Output is clamped at the size header.
 #pragma once
 
-#include "tsq_common.cuh"
+#include "../tsq_common.cuh"
+#include "../tsq_dec_common.cuh"
 
 namespace tsq {
 
@@ -42,12 +43,6 @@ struct DecCfg {
     static constexpr uint16_t RES = 0xFFFF;    // "byte already final" marker in the pointer table
 };
 
-struct DecSym {            // 8 bytes
-    uint16_t out_rel;      // position inside the chunk image
-    uint8_t len;           // bytes to produce (already clamped at the block size)
-    uint8_t kind;          // 0 none, 1 literal, 2 match
-    uint32_t a;            // literal: chunk-relative stream offset; match: block-absolute source position
-};
 
 // LDS layout (bytes).  The symbol records reuse the doubling tables, which are dead after P4.
 struct DecLds {
@@ -70,16 +65,6 @@ struct DecLds {
 static_assert(8 * DecCfg::MAXG * sizeof(DecSym) <= 6 * DecCfg::S, "symbol records must fit the dead tables");
 static_assert(DecLds::total <= 160 * 1024, "LDS budget");
 
-#ifdef TSQ_STATS
-__device__ unsigned long long g_dec_stats[16];
-#define TSQD_T0() unsigned long long t0_ = __builtin_amdgcn_s_memtime()
-#define TSQD_ACC(slot) do { unsigned long long t1_ = __builtin_amdgcn_s_memtime(); st_[slot] += t1_ - t0_; t0_ = t1_; } while (0)
-#define TSQD_CNT(slot, v) st_[slot] += (v)
-#else
-#define TSQD_T0() do {} while (0)
-#define TSQD_ACC(slot) do {} while (0)
-#define TSQD_CNT(slot, v) do {} while (0)
-#endif
 
 __global__ __launch_bounds__(DecCfg::T) void dec_fast_kernel(const uint8_t* __restrict__ container,
                                                              const FrameInfo* __restrict__ frames,

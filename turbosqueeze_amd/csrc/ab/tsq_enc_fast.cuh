@@ -1,4 +1,4 @@
-// tsq_enc_fast.cuh -- wave-window block encoder for gfx950 (kernel variant 0).
+// tsq_enc_fast.cuh -- wave-window block encoder for gfx950 (A/B variant 2: superseded, not in the product library).
 //
 // The reference parse (tsq_encode.cpp:48-342) is a greedy walk in which every decision depends on
 // the hash table, and the table depends on which positions the walk visited -- the walk itself is
@@ -25,109 +25,13 @@
 // at visit time from the visited mask; everything else runs on the precomputed registers.
 #pragma once
 
-#include "tsq_common.cuh"
+#include "../tsq_common.cuh"
+#include "../tsq_enc_util.cuh"
+#include "../tsq_enc_builder.cuh"
 
 namespace tsq {
 
 constexpr uint32_t kEncLds = kHashEntries;          // u8 per bucket: which lane wrote it in this window
-
-// Instrumented builds (-DTSQ_STATS, make stats): block 0 publishes cycle and event counters.
-#ifdef TSQ_STATS
-__device__ unsigned long long g_enc_stats[48];
-#define TSQ_T0() unsigned long long t0_ = __builtin_amdgcn_s_memtime()
-#define TSQ_ACC(slot) do { unsigned long long t1_ = __builtin_amdgcn_s_memtime(); st_[slot] += t1_ - t0_; t0_ = t1_; } while (0)
-#define TSQ_CNT(slot, v) st_[slot] += (v)
-#define TSQ_SUB(slot) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); TSQ_ACC(slot); } while (0)
-#else
-#ifdef TSQ_MARKS
-#define TSQ_ACC(slot) asm volatile("; TSQ_MARK " #slot ::: "memory")
-#else
-#define TSQ_ACC(slot) do {} while (0)
-#endif
-#define TSQ_T0() do {} while (0)
-#define TSQ_CNT(slot, v) do {} while (0)
-#define TSQ_SUB(slot) TSQ_ACC(slot)
-#endif
-
-// 16 bytes at src+at, zeros past `avail`
-__device__ __forceinline__ uint4 ld128z(const uint8_t* src, uint64_t at, uint64_t avail)
-{
-    uint4 v;
-    if (__builtin_expect(at + 16 <= avail, 1)) { __builtin_memcpy(&v, src + at, 16); return v; }
-    uint32_t w[4] = {0, 0, 0, 0};
-#pragma nounroll
-    for (uint32_t k = 0; k < 16; ++k) if (at + k < avail) w[k >> 2] |= (uint32_t)src[at + k] << (8u * (k & 3u));
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-__device__ __forceinline__ uint32_t prefix16(uint4 a, uint4 b)
-{
-    uint32_t k = prefix8((uint64_t)a.x | ((uint64_t)a.y << 32), (uint64_t)b.x | ((uint64_t)b.y << 32));
-    if (k == 8) k += prefix8((uint64_t)a.z | ((uint64_t)a.w << 32), (uint64_t)b.z | ((uint64_t)b.w << 32));
-    return k;
-}
-
-__device__ __forceinline__ uint64_t below(uint32_t bit) { return bit >= 64u ? ~0ull : (1ull << bit) - 1ull; }
-__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
-
-// Symbol records (one u32 per symbol):
-//   literal: bit 31 = 1, bits 22..25 = length-1, bits 0..21 = input position of the first byte
-//   match:   bit 31 = 0, bits 16..19 = size nibble, bits 0..15 = offset
-__device__ __forceinline__ uint32_t rec_literal(uint32_t pos, uint32_t len) { return 0x80000000u | ((len - 1u) << 22) | pos; }
-__device__ __forceinline__ uint32_t rec_match(uint32_t offset, uint32_t nib) { return (nib << 16) | offset; }
-
-// Lay out and store the `cnt` (<= 64) symbols held one per lane in `rec`, starting at output
-// position j0 which is the start of a group of 8 (tsq_encode.cpp:57-59,94-95: control byte, then per
-// pair a size byte and the two payloads).  Returns the output position after the last payload.
-// lit_out / lit_src report the last literal chunk of the batch (for the never-filled trailing
-// bytes); lit_out == 0xFFFFFFFF when the batch holds no literal.  Not inlined: it runs once per
-// 64 symbols and must not bloat the walk loop; the caller re-uniforms the results.
-struct EmitResult { uint32_t end, lit_out, lit_src; };
-__device__ __noinline__ EmitResult emit_batch(uint32_t rec, uint32_t cnt, uint32_t j0, uint8_t* out, const uint8_t* src,
-                                              uint64_t avail, uint32_t lane)
-{
-    uint32_t lit_out = 0xFFFFFFFFu, lit_src = 0;
-    const bool live = lane < cnt;
-    const uint32_t lit = live ? rec >> 31 : 1u;                   // padding symbols count as literals (tsq_encode.cpp:180)
-    const uint32_t nib = live ? (lit ? (rec >> 22) & 15u : (rec >> 16) & 15u) : 0u;
-    const uint32_t pay = live ? (lit ? nib + 1u : 2u) : 0u;
-    const uint32_t extra = live ? (uint32_t)((lane & 7u) == 0u) + (uint32_t)((lane & 1u) == 0u) : 0u;
-    uint32_t incl = pay + extra;
-#pragma unroll
-    for (uint32_t d = 1; d < 64; d <<= 1) { uint32_t up = __shfl_up(incl, d); if (lane >= d) incl += up; }
-    const uint32_t at = j0 + incl - (pay + extra);                // where this symbol's control/size/payload region starts
-    const uint32_t end = j0 + rdlane(incl, 63);
-
-    const uint64_t lits = __ballot(lit != 0u);
-    if (live && (lane & 7u) == 0u) {                               // control byte: first symbol of the group in bit 7
-        uint32_t bits = (uint32_t)(lits >> lane) & 0xFFu;
-        bits = __builtin_bitreverse32(bits) >> 24;
-        out[at] = (uint8_t)bits;
-    }
-    const uint32_t nib_next = __shfl_down(nib, 1);
-    if (live && (lane & 1u) == 0u) out[at + (uint32_t)((lane & 7u) == 0u)] = (uint8_t)((nib << 4) | nib_next);
-    const uint32_t pay_at = at + extra;
-    if (live) {
-        if (lit) {
-            const uint32_t pos = rec & 0x3FFFFFu;
-            const uint4 v = ld128z(src, pos, avail);
-            const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (uint32_t t = 0; t < 16; ++t)
-                if (t <= nib) out[pay_at + t] = (uint8_t)(wds[t >> 2] >> (8u * (t & 3u)));
-        } else {
-            const uint16_t off = (uint16_t)rec;
-            __builtin_memcpy(out + pay_at, &off, 2);
-        }
-    }
-    const uint64_t live_lits = lits & below(cnt);
-    if (live_lits) {
-        const uint32_t last = 63u - (uint32_t)__builtin_clzll(live_lits);
-        lit_out = rdlane(pay_at, last);
-        lit_src = rdlane(rec, last) & 0x3FFFFFu;
-    }
-    return EmitResult{end, lit_out, lit_src};
-}
 
 template <bool EXT>
 __global__ __launch_bounds__(64) void enc_fast_kernel(const uint8_t* __restrict__ in, uint64_t n_total, uint64_t readable,

@@ -1,4 +1,4 @@
-// tsq_enc_orbit.cuh -- "orbit" block encoder for gfx950 (kernel variant 0).
+// tsq_enc_orbit.cuh -- "orbit" block encoder for gfx950 (A/B variant 3: superseded, not in the product library).
 //
 // Same window structure as tsq_enc_fast.cuh (64 positions per window, one wavefront per block,
 // gathers for candidate + common prefix per lane), but the serial part of the parse is reduced to
@@ -27,25 +27,14 @@
 // Symbol records go to a 128-entry LDS ring; every 64 symbols emit_batch() lays them out.
 #pragma once
 
-#include "tsq_common.cuh"
-#include "tsq_enc_fast.cuh"     // ld128z, prefix16, rdlane, below, rec_*, emit_batch, TSQ_* stats macros
+#include "../tsq_common.cuh"
+#include "../tsq_enc_util.cuh"
+#include "../tsq_enc_builder.cuh"
 
 namespace tsq {
 
 constexpr uint32_t kOrbRing = 128;
 constexpr uint32_t kOrbLds = kHashEntries + kOrbRing * 4;
-
-#ifdef TSQ_STATS
-__device__ uint32_t g_dbg_syms[8192];
-#endif
-__device__ __forceinline__ uint32_t msb64(uint64_t m) { return 63u - (uint32_t)__builtin_clzll(m); }
-__device__ __forceinline__ uint32_t lsb64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
-// number of consecutive set bits of `mask` starting at bit `from` (a run that reaches bit 63 included)
-__device__ __forceinline__ uint32_t ones_from(uint64_t mask, uint32_t from)
-{
-    const uint64_t inv = ~(mask >> from);            // zero only when from == 0 and every bit is set
-    return inv ? (uint32_t)__builtin_ctzll(inv) : 64u - from;
-}
 
 template <bool EXT>
 __global__ __launch_bounds__(64) void enc_orbit_kernel(const uint8_t* __restrict__ in, uint64_t n_total, uint64_t readable,

@@ -1,4 +1,4 @@
-// tsq_enc_pipe.cuh -- two-wave pipelined block encoder for gfx950 (kernel variant 0).
+// tsq_enc_pipe.cuh -- two-wave pipelined block encoder for gfx950 (A/B variant 4: superseded, not in the product library).
 //
 // One workgroup of two wavefronts per 4 MiB block, specialised by role; they run on different
 // SIMDs of the CU, so their instruction streams issue concurrently (a lone wavefront issues about
@@ -18,7 +18,9 @@
 // the parser; everything that is a pure function of the parse moved to the builder.
 #pragma once
 
-#include "tsq_common.cuh"
+#include "../tsq_common.cuh"
+#include "../tsq_enc_util.cuh"
+#include "../tsq_enc_builder.cuh"
 #include "tsq_enc_orbit.cuh"
 
 namespace tsq {
@@ -33,13 +35,7 @@ struct PipeCfg {
     static constexpr uint32_t off_ctl = off_ring + RING * 4;                   // u32[4]: head, tail
     static constexpr uint32_t total = off_ctl + 64;
 };
-enum : uint32_t { kItemSeg = 1, kItemSym = 2, kItemEnd = 3 };
-// LDS pointers with an explicit address space: volatile accesses through a generic pointer are
-// not rewritten by address-space inference and would compile to flat_* plus a vmcnt(0) wait each.
-typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
-typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
-// item header words: 0 kind, 1 base, 2 V lo, 3 V hi, 4 nsym at entry, 5 origin at entry, 6 lit_from at entry,
-// 7 certain lo, 8 certain hi, 9 record (kItemSym)        lane words: cand0 | nibble << 24
+
 
 // The orbit: L += span[L] until a stop lane (span >= 128) or the end of the window, collecting
 // the visited lanes.  Hand-written because hipcc turns the equivalent C++ loop into ~18 scalar
@@ -325,120 +321,6 @@ __device__ __forceinline__ void pipe_parser(const uint8_t* src, uint64_t avail, 
     }
 }
 
-template <class Cfg>
-__device__ __forceinline__ void pipe_builder(const uint8_t* src, uint64_t avail, uint8_t* out, lds_u8_t* lds, uint32_t lane,
-                                             uint32_t b, uint32_t* sizes, int32_t* status)
-{
-    using PipeCfg = Cfg;
-    volatile lds_u32_t* queue = (volatile lds_u32_t*)(lds + PipeCfg::off_queue);
-    volatile lds_u32_t* ring = (volatile lds_u32_t*)(lds + PipeCfg::off_ring);
-    lds_u32_t* ctl = (lds_u32_t*)(lds + PipeCfg::off_ctl);
-    uint32_t tail = 0, nsym = 0, j0 = 3, lit_out = 0xFFFFFFFFu, lit_src = 0;
-    bool overflow = false;
-
-    auto flush_batch = [&](uint32_t first_index, uint32_t cnt) {
-        if (overflow) return;
-        const uint32_t rec = ring[(first_index + lane) & (PipeCfg::RING - 1u)];
-        const EmitResult r = emit_batch(rec, cnt, j0, out, src, avail, lane);
-        j0 = uniform(r.end);
-        const uint32_t lo = uniform(r.lit_out);
-        if (lo != 0xFFFFFFFFu) { lit_out = lo; lit_src = uniform(r.lit_src); }
-        if (j0 + 1200u > kSlotSize) overflow = true;
-    };
-
-#ifdef TSQ_STATS
-    unsigned long long st_[32] = {0};
-#endif
-#ifdef TSQ_STATS
-    const unsigned long long begin_ = __builtin_amdgcn_s_memtime();
-#endif
-    for (;;) {
-        if (__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == tail) {
-#ifdef TSQ_STATS
-            const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
-#endif
-            while (__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == tail) __builtin_amdgcn_s_sleep(1);
-#ifdef TSQ_STATS
-            st_[17] += __builtin_amdgcn_s_memtime() - w0_;
-#endif
-        }
-        volatile lds_u32_t* it = queue + (tail % PipeCfg::Q) * PipeCfg::ITEM_WORDS;
-        const uint32_t kind = uniform(it[0]);
-        const uint32_t nsym_entry = uniform(it[4]);
-        uint32_t nsym_after = nsym_entry;
-        if (kind == kItemSym) {
-            if (lane == 0) ring[nsym_entry & (PipeCfg::RING - 1u)] = it[9];
-            nsym_after = nsym_entry + 1u;
-        } else if (kind == kItemSeg) {
-            const uint32_t base = uniform(it[1]);
-            const uint64_t V = (uint64_t)uniform(it[2]) | ((uint64_t)uniform(it[3]) << 32);
-            const uint32_t origin_entry = uniform(it[5]);
-            uint32_t lit_from = uniform(it[6]);
-            const uint64_t certain_m = (uint64_t)uniform(it[7]) | ((uint64_t)uniform(it[8]) << 32);
-            const uint32_t lane_word = it[16 + lane];
-            const uint32_t cand0 = lane_word & 0xFFFFFFu, nib = lane_word >> 24;
-            const uint32_t p = base + lane;
-            const uint64_t M = V & certain_m, N = V & ~certain_m;
-            const uint32_t Ls = lsb64(V);
-            uint32_t idx0 = nsym_entry;
-            if (((M >> Ls) & 1ull) && lit_from < base + Ls) {
-                // a literal run ended exactly at the segment boundary: its pending bytes close here
-                if (lane == 0) ring[idx0 & (PipeCfg::RING - 1u)] = rec_literal(lit_from, base + Ls - lit_from);
-                idx0++;
-                lit_from = base + Ls;
-            }
-            // the pair origin seen by an odd first symbol: the parser's origin, unless the literal above was symbol idx0-1
-            const uint32_t first_prev_start = (idx0 != nsym_entry) ? uniform(it[6]) : origin_entry;
-            const uint32_t len_first = ((N >> Ls) & 1ull) ? ones_from(N, Ls) : 0u;
-            const uint64_t startN = N & ~(N << 1);
-            const bool isM = (M >> lane) & 1ull, isN = (N >> lane) & 1ull;
-            const bool in_first = lane >= Ls && lane < Ls + len_first;
-            const uint64_t sb = startN & below(lane + 1u);
-            const uint32_t rs_lane = sb ? msb64(sb) : 0u;
-            const uint32_t rs_pos = in_first ? lit_from : base + rs_lane;
-            const uint32_t off = p - rs_pos;
-            const bool next_isM = lane < 63u && ((M >> (lane + 1u)) & 1ull);
-            const bool ownerN = isN && ((off & 15u) == 15u || next_isM);
-            const bool sym = isM || ownerN;
-            const uint64_t SS = __ballot(sym);
-            const uint64_t before = SS & below(lane);
-            const uint32_t idx = idx0 + (uint32_t)__builtin_popcountll(before);
-            const uint32_t sym_start = isM ? p : p - (off & 15u);
-            const uint32_t prev_start_v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((before ? msb64(before) : 0u) << 2), (int)sym_start);
-            const uint32_t pair_origin = (idx & 1u) ? (before ? prev_start_v : first_prev_start) : sym_start;
-            if (sym) ring[idx & (PipeCfg::RING - 1u)] = isM ? rec_match(pair_origin - cand0, nib) : rec_literal(sym_start, (off & 15u) + 1u);
-            nsym_after = idx0 + (uint32_t)__builtin_popcountll(SS);
-        }
-        // the item is consumed: release the slot before the (long) flush
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        tail++;
-        __hip_atomic_store(&ctl[1], tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (kind == kItemEnd) { nsym = nsym_entry; break; }
-        if ((nsym ^ nsym_after) & ~63u) flush_batch((nsym_after & ~63u) - 64u, 64u);
-        nsym = nsym_after;
-    }
-#ifdef TSQ_STATS
-    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[17] = st_[17]; g_enc_stats[18] = __builtin_amdgcn_s_memtime() - begin_; }
-#endif
-
-    if (overflow) { if (lane == 0) { atomicMax(status, kErrOverflow); sizes[b] = 3; } return; }
-    const uint32_t rest = nsym & 63u;
-    if (rest) flush_batch(nsym - rest, rest);
-    auto stale = [&](uint32_t pos) -> uint32_t {
-        const uint32_t d = pos - lit_out;
-        return (lit_out != 0xFFFFFFFFu && d < 16u) ? ldu8z(src, (uint64_t)lit_src + d, avail) : 0u;
-    };
-    uint32_t total = j0;
-    if ((nsym & 7u) == 0u) {
-        if (lane == 0) { out[j0] = (uint8_t)stale(j0); out[j0 + 1] = (uint8_t)stale(j0 + 1); }
-        total = j0 + 2;
-    } else if ((nsym & 1u) == 0u) {
-        if (lane == 0) out[j0] = (uint8_t)(stale(j0) << 4);
-        total = j0 + 1;
-    }
-    if (lane == 0) sizes[b] = total;
-}
-
 template <bool EXT>
 __global__ __launch_bounds__(128) void enc_pipe_kernel(const uint8_t* __restrict__ in, uint64_t n_total, uint64_t readable,
                                                        uint8_t* __restrict__ slots, uint32_t* __restrict__ sizes,
@@ -463,7 +345,7 @@ __global__ __launch_bounds__(128) void enc_pipe_kernel(const uint8_t* __restrict
     __syncthreads();
     lds_u8_t* lds3 = (lds_u8_t*)pipe_lds;
     if (role == 0) pipe_parser<EXT>(src, avail, n, table, lds3, lane, b);
-    else pipe_builder<PipeCfg>(src, avail, out, lds3, lane, b, sizes, status);
+    else stream_builder<PipeCfg>(src, avail, out, lds3, lane, b, sizes, status);
 }
 
 }  // namespace tsq

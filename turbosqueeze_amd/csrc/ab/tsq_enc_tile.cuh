@@ -1,4 +1,4 @@
-// tsq_enc_tile.cuh -- three-wave tile-pipelined block encoder for gfx950 (kernel variant 0).
+// tsq_enc_tile.cuh -- three-wave tile-pipelined block encoder for gfx950 (A/B variant 5: superseded, not in the product library).
 //
 // One workgroup of three wavefronts per 4 MiB block, each on its own SIMD:
 //
@@ -20,7 +20,7 @@
 // this tile?).
 #pragma once
 
-#include "tsq_common.cuh"
+#include "../tsq_common.cuh"
 #include "tsq_enc_pipe.cuh"
 
 namespace tsq {
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(192) void enc_tile_kernel(const uint8_t* __restrict
     lds_u8_t* lds3 = (lds_u8_t*)tile_lds;
     if (role == 0) tile_front<EXT>(src, avail, n, table, lds3, lane);
     else if (role == 1) tile_parser<EXT>(src, avail, n, lds3, lane);
-    else pipe_builder<TileCfg>(src, avail, out, lds3, lane, b, sizes, status);
+    else stream_builder<TileCfg>(src, avail, out, lds3, lane, b, sizes, status);
 }
 
 }  // namespace tsq

@@ -16,6 +16,7 @@
 #include "../../include/turbosqueeze.h"
 
 #include <sys/mman.h>
+#include <sys/uio.h>
 #include <unistd.h>
 #include <atomic>
 #include <chrono>
@@ -198,6 +199,7 @@ struct Lane {
     tsqa_ctx* dev = nullptr;
     uint8_t *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
     FrameInfo* h_frames = nullptr;
+    uint64_t* h_frame_at = nullptr;                            // pinned: frame offsets of a compressed batch (n_frames + 1)
     size_t in_cap = 0, out_cap = 0, frames_cap = 0, h_in_cap = 0, h_out_cap = 0;
     uint64_t* h_size = nullptr; int32_t* h_status = nullptr;   // pinned result words
     hipEvent_t ev = nullptr;
@@ -236,7 +238,9 @@ struct Lane {
         }
         if (n_frames > frames_cap) {
             (void)hipHostFree(h_frames); h_frames = nullptr; frames_cap = 0;
+            (void)hipHostFree(h_frame_at); h_frame_at = nullptr;
             if (hipHostMalloc(&h_frames, n_frames * sizeof(FrameInfo), hipHostMallocPortable) != hipSuccess) return false;
+            if (hipHostMalloc(&h_frame_at, (n_frames + 1) * sizeof(uint64_t), hipHostMallocPortable) != hipSuccess) return false;
             frames_cap = n_frames;
         }
         return true;
@@ -244,7 +248,7 @@ struct Lane {
     void destroy() {
         if (dev) (void)hipSetDevice(dev->device);
         if (ev) (void)hipEventDestroy(ev);
-        (void)hipHostFree(h_in); (void)hipHostFree(h_out); (void)hipHostFree(h_frames);
+        (void)hipHostFree(h_in); (void)hipHostFree(h_out); (void)hipHostFree(h_frames); (void)hipHostFree(h_frame_at);
         (void)hipHostFree(h_size); (void)hipHostFree(h_status);
         (void)hipFree(d_in); (void)hipFree(d_out);
         tsqa_destroy(dev);
@@ -270,6 +274,7 @@ public:
 
     bool start() {
         std::vector<int> devs = device_list();
+        n_devices_ = (uint32_t)devs.size();
         size_t per_dev = env_size("TSQ_AMD_LANES", 2);
         for (size_t k = 0; k < per_dev * devs.size(); ++k) {
             Lane l;
@@ -308,6 +313,22 @@ public:
     }
 
 private:
+    // Blocks per batch for a job of nb blocks.  A batch is what one device works on at a time, so a job that would fit
+    // one batch is still cut into one slice of consecutive blocks per listed device (the analogue of block i ->
+    // worker i % num_cores, tsq_threads.cpp:71,463, at slice granularity: each slice carries its 128-byte look-ahead,
+    // and the host gathers the slices in block order).
+    uint32_t job_batch(uint32_t nb, bool through_files) const {
+        uint32_t batch = through_files ? file_batch_blocks_ : batch_blocks_;
+        if (n_devices_ > 1) {
+            const uint32_t per_dev = (nb + n_devices_ - 1) / n_devices_;
+            if (per_dev < batch) batch = per_dev ? per_dev : 1;
+        }
+        return batch;
+    }
+    // Blocks per device-to-host piece: progress is reported per block as its bytes land; a piece of a few blocks keeps
+    // the copies large enough for the DMA engines (one 4 MiB block per copy costs about a third of the bandwidth).
+    static uint32_t progress_piece(uint32_t n_blocks) { return n_blocks >= 64 ? 8u : n_blocks >= 8 ? 2u : 1u; }
+
     void loop() {
         for (;;) {
             Job j;
@@ -348,7 +369,7 @@ private:
         std::deque<InFlight> fly;
         uint32_t done_blocks = 0;
         const bool stage_in = src.mem == nullptr, stage_out = sink.mem == nullptr;
-        const uint32_t batch = (stage_in || stage_out) ? file_batch_blocks_ : batch_blocks_;
+        const uint32_t batch = job_batch(nb, stage_in || stage_out);
         Marks mk; mk.at("compress: buffers opened");
         Prefault touch;
         if (!stage_out) touch.start(sink.mem, sink.cap < total ? sink.cap : total);   // (the bound is 1.25x; text lands at 0.6x)
@@ -360,22 +381,30 @@ private:
             size_t sz = (size_t)*l.h_size;                            // batch container: 16-byte header + frames
             mk.at("compress: kernels done");
             if (sz < 16 || sz > l.out_cap) { ok = false; return; }
-            if (stage_out) {
-                if (hipMemcpyAsync(l.h_out, l.d_out + 16, sz - 16, hipMemcpyDeviceToHost, l.dev->stream) != hipSuccess ||
-                    hipStreamSynchronize(l.dev->stream) != hipSuccess) { ok = false; return; }
-                sink.write(l.h_out, sz - 16);
-            } else {
-                touch.join();
-                mk.at("compress: output pages touched");
-                uint8_t* dst = sink.claim(sz - 16);                   // frames land in the caller's buffer directly
-                if (!dst || hipMemcpyAsync(dst, l.d_out + 16, sz - 16, hipMemcpyDeviceToHost, l.dev->stream) != hipSuccess ||
-                    hipStreamSynchronize(l.dev->stream) != hipSuccess) { ok = false; return; }
+            if (!stage_out) { touch.join(); mk.at("compress: output pages touched"); }
+            // The frames come back in pieces of a few blocks, in block order, and every block reports progress as soon as
+            // its bytes have landed (tsq_threads.cpp:226-254: the writer emits a frame, then calls progress_cb).
+            const uint64_t* fat = l.h_frame_at;                       // frame offsets inside the batch container
+            const uint32_t piece = progress_piece(f.n_blocks);
+            for (uint32_t p0 = 0; p0 < f.n_blocks && ok; p0 += piece) {
+                const uint32_t p1 = p0 + piece < f.n_blocks ? p0 + piece : f.n_blocks;
+                const size_t from = (size_t)fat[p0], len = (size_t)fat[p1] - from;
+                if (from < 16 || from + len > sz) { ok = false; return; }
+                if (stage_out) {
+                    if (hipMemcpyAsync(l.h_out, l.d_out + from, len, hipMemcpyDeviceToHost, l.dev->stream) != hipSuccess ||
+                        hipStreamSynchronize(l.dev->stream) != hipSuccess) { ok = false; return; }
+                    sink.write(l.h_out, len);
+                } else {
+                    uint8_t* dst = sink.claim(len);                   // frames land in the caller's buffer directly
+                    if (!dst || hipMemcpyAsync(dst, l.d_out + from, len, hipMemcpyDeviceToHost, l.dev->stream) != hipSuccess ||
+                        hipStreamSynchronize(l.dev->stream) != hipSuccess) { ok = false; return; }
+                }
+                for (uint32_t b = p0; b < p1; ++b) {                  // tsq_threads.cpp:248-254
+                    done_blocks++;
+                    if (j.progress) j.progress(j.id, (double)done_blocks / (double)nb);
+                }
             }
             mk.at("compress: D2H done");
-            for (uint32_t b = 0; b < f.n_blocks; ++b) {               // tsq_threads.cpp:248-254
-                done_blocks++;
-                if (j.progress) j.progress(j.id, (double)done_blocks / (double)nb);
-            }
         };
 
         for (uint32_t b0 = 0, k = 0; b0 < nb && ok; b0 += batch, ++k) {
@@ -387,7 +416,7 @@ private:
             const size_t at = (size_t)b0 * kBlockSize;
             const size_t want = (size_t)bn * kBlockSize;
             const size_t n = total - at < want ? total - at : want;
-            if (!l.reserve(want + kHalo, tsqa_container_bound(want), 0, stage_in, stage_out)) { ok = false; break; }
+            if (!l.reserve(want + kHalo, tsqa_container_bound(want), bn, stage_in, stage_out)) { ok = false; break; }
             (void)hipSetDevice(l.dev->device);
             hipStream_t s = l.dev->stream;
             // the batch plus the first bytes of the next one: block k's look-ahead reads block k+1
@@ -402,12 +431,14 @@ private:
             if (l.dev->launch_encode(l.d_in, n, got, j.ext ? 1u : 0u, l.dev->d_status, s) != TSQA_OK) { ok = false; break; }
             if (l.dev->launch_pack(n, j.ext ? 1u : 0u, l.d_out, l.out_cap, l.dev->d_size, l.dev->d_status, s) != TSQA_OK) { ok = false; break; }
             (void)hipMemcpyAsync(l.h_size, l.dev->d_size, sizeof(uint64_t), hipMemcpyDeviceToHost, s);
+            (void)hipMemcpyAsync(l.h_frame_at, l.dev->frame_at, (bn + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s);
             (void)hipMemcpyAsync(l.h_status, l.dev->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s);
             if (hipEventRecord(l.ev, s) != hipSuccess) { ok = false; break; }
             fly.push_back({lane_i, b0, bn, 0});
         }
         while (ok && !fly.empty()) drain_one();
         for (auto& l : lanes_) { (void)hipSetDevice(l.dev->device); (void)hipStreamSynchronize(l.dev->stream); }
+        touch.join();                                                 // nobody may still be touching the buffer when it is freed
         if (!sink.finish()) ok = false;
         if (!j.outfile) {
             if (ok) { *j.out = sink.mem; *j.szout = sink.at; }       // tsq_threads.cpp:375-379; caller free()s
@@ -425,7 +456,10 @@ private:
         uint32_t nb; uint64_t total;
         memcpy(&nb, header + 4, 4); memcpy(&total, header + 8, 8);
         if (nb == 0) return false;                                                             // tsq_threads.cpp:759-768
-        if ((uint64_t)nb * kBlockSize < total) return false;
+        // The header is not trusted with an allocation before it has been held against the container: a frame is at
+        // least 6 bytes, a block at most 4 MiB, and no stream expands more than 64x (eight 64-byte copies per 13-byte group).
+        if ((uint64_t)nb > (src.size - 16) / 6) return false;
+        if ((uint64_t)nb * kBlockSize < total || total / 64 > src.size) return false;
         Sink sink;
         if (j.outfile) { if (!sink.open_file_buffered(j.out_path.c_str(), (size_t)total + 128)) return false; }
         else if (!sink.open_mem((size_t)total + 128)) return false;                            // tsq_threads.cpp:795
@@ -434,40 +468,58 @@ private:
         std::deque<InFlight> fly;
         uint32_t done_blocks = 0;
         const bool stage_in = src.mem == nullptr, stage_out = sink.mem == nullptr;
-        const uint32_t batch = (stage_in || stage_out) ? file_batch_blocks_ : batch_blocks_;
+        const uint32_t batch = job_batch(nb, stage_in || stage_out);
         Prefault touch;
-        if (!stage_out) touch.start(sink.mem, (size_t)total);
+        bool touching = false;
         auto drain_one = [&]() {
             InFlight f = fly.front(); fly.pop_front();
             Lane& l = lanes_[f.lane];
             (void)hipSetDevice(l.dev->device);
             if (hipEventSynchronize(l.ev) != hipSuccess || *l.h_status != 0) { ok = false; return; }
-            if (stage_out) sink.write(l.h_out, f.out_bytes);          // (memory sinks: the copy landed in place)
-            for (uint32_t b = 0; b < f.n_blocks; ++b) {                // tsq_threads.cpp:654-655
-                done_blocks++;
-                if (j.progress) j.progress(j.id, (double)done_blocks / (double)nb);
+            // the blocks come back in pieces of a few blocks, in order; each block reports progress once it has landed
+            // (tsq_threads.cpp:648-655: the writer copies a block out, then calls progress_cb)
+            if (!stage_out) touch.join();
+            uint8_t* dst = stage_out ? nullptr : sink.claim(f.out_bytes);
+            if (!stage_out && !dst) { ok = false; return; }
+            const FrameInfo* fr = l.h_frames;
+            const uint32_t piece = progress_piece(f.n_blocks);
+            for (uint32_t p0 = 0; p0 < f.n_blocks && ok; p0 += piece) {
+                const uint32_t p1 = p0 + piece < f.n_blocks ? p0 + piece : f.n_blocks;
+                const size_t from = (size_t)fr[p0].out_at;
+                const size_t len = (size_t)(fr[p1 - 1].out_at + fr[p1 - 1].out_len) - from;
+                uint8_t* to = stage_out ? l.h_out : dst + from;
+                if (hipMemcpyAsync(to, l.d_out + from, len, hipMemcpyDeviceToHost, l.dev->stream) != hipSuccess ||
+                    hipStreamSynchronize(l.dev->stream) != hipSuccess) { ok = false; return; }
+                if (stage_out) sink.write(l.h_out, len);
+                for (uint32_t b = p0; b < p1; ++b) {
+                    done_blocks++;
+                    if (j.progress) j.progress(j.id, (double)done_blocks / (double)nb);
+                }
             }
         };
 
         size_t at = 16;                       // container cursor: the frame walk is serial (tsq_threads.cpp:513-524)
         uint64_t produced = 0;
-        const size_t in_budget = (size_t)batch * (3 + kSlotSize);
         for (uint32_t b0 = 0, k = 0; b0 < nb && ok; ++k) {
             const size_t lane_i = k % lanes_.size();
             while (ok && fly.size() >= lanes_.size()) drain_one();
             if (!ok) break;
             Lane& l = lanes_[lane_i];
-            if (!l.reserve(in_budget + 16, (size_t)batch * kBlockSize + 256, batch, stage_in, stage_out)) { ok = false; break; }
+            // sized by what is left of the job, not by the configured batch (a one-block container must not reserve gigabytes)
+            const uint32_t want_blocks = nb - b0 < batch ? nb - b0 : batch;
+            size_t in_budget = (size_t)want_blocks * (3 + kSlotSize);
+            if (in_budget > src.size - at) in_budget = src.size - at;
+            if (!l.reserve(in_budget + 16, (size_t)want_blocks * kBlockSize + 256, want_blocks, stage_in, stage_out)) { ok = false; break; }
             // walk whole frames until the batch is full; the frames of a batch are one contiguous slice of the container
             size_t cur = 0; uint32_t bn = 0; size_t out_bytes = 0;
-            while (b0 + bn < nb && bn < batch) {
+            while (b0 + bn < nb && bn < want_blocks) {
                 uint8_t fh[6];
                 if (src.read_at(at + cur, 6, fh) != 6) break;
                 uint32_t frame = (uint32_t)fh[0] | ((uint32_t)fh[1] << 8) | ((uint32_t)fh[2] << 16);
                 uint32_t len = frame & 0x7FFFFFu;                                             // tsq_threads.cpp:513-517
                 if (len < 3 || len > kSlotSize) { ok = false; break; }                         // tsq_threads.cpp:526-531
-                if (cur + 3 + len > l.in_cap) break;
                 if (at + cur + 3 + len > src.size) { ok = false; break; }
+                if (cur + 3 + len > l.in_cap) break;
                 if (stage_in) {
                     memcpy(l.h_in + cur, fh, 3);
                     if (src.read_at(at + cur + 3, len, l.h_in + cur + 3) != len) { ok = false; break; }
@@ -480,6 +532,8 @@ private:
             }
             if (!ok) break;
             if (bn == 0) { ok = false; break; }                        // truncated container
+            // the result buffer is made resident only now that a first batch of frames has been found well formed
+            if (!stage_out && !touching) { touch.start(sink.mem, (size_t)total); touching = true; }
             (void)hipSetDevice(l.dev->device);
             hipStream_t s = l.dev->stream;
             if (l.dev->reserve(bn, false) != TSQA_OK) { ok = false; break; }
@@ -487,12 +541,6 @@ private:
             if (hipMemcpyAsync(l.dev->frames, l.h_frames, bn * sizeof(FrameInfo), hipMemcpyHostToDevice, s) != hipSuccess) { ok = false; break; }
             if (hipMemsetAsync(l.dev->d_status, 0, sizeof(int32_t), s) != hipSuccess) { ok = false; break; }
             if (l.dev->launch_decode(l.d_in, bn, l.d_out, l.dev->d_status, s) != TSQA_OK) { ok = false; break; }
-            if (stage_out) (void)hipMemcpyAsync(l.h_out, l.d_out, out_bytes, hipMemcpyDeviceToHost, s);
-            else {
-                touch.join();
-                uint8_t* dst = sink.claim(out_bytes);                  // blocks land in the caller's buffer directly
-                if (!dst || hipMemcpyAsync(dst, l.d_out, out_bytes, hipMemcpyDeviceToHost, s) != hipSuccess) { ok = false; break; }
-            }
             (void)hipMemcpyAsync(l.h_status, l.dev->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s);
             if (hipEventRecord(l.ev, s) != hipSuccess) { ok = false; break; }
             fly.push_back({lane_i, b0, bn, out_bytes});
@@ -500,6 +548,7 @@ private:
         }
         while (ok && !fly.empty()) drain_one();
         for (auto& l : lanes_) { (void)hipSetDevice(l.dev->device); (void)hipStreamSynchronize(l.dev->stream); }
+        touch.join();                                                 // nobody may still be touching the buffer when it is freed
         if (ok && produced != total) ok = false;
         if (!sink.finish()) ok = false;
         if (!j.outfile) {
@@ -511,7 +560,7 @@ private:
 
     const bool compress_, verbose_;
     std::vector<Lane> lanes_;
-    uint32_t batch_blocks_ = 512, file_batch_blocks_ = 64;
+    uint32_t batch_blocks_ = 512, file_batch_blocks_ = 64, n_devices_ = 1;
     std::thread thread_;
     std::mutex m_;
     std::condition_variable cv_, idle_cv_;
@@ -616,9 +665,20 @@ extern "C" void tsqEncode(struct TSQCompressionContext* ctx, uint8_t* inputBlock
     (void)hipSetDevice(l.dev->device);
     hipStream_t s = l.dev->stream;
     memcpy(l.h_in, inputBlock, inputSize);
-    if (hipMemcpyAsync(l.d_in, l.h_in, inputSize, hipMemcpyHostToDevice, s) != hipSuccess) return;
+    // The reference's encoder reads up to ~67 bytes past inputBlock[inputSize-1] (tsq_encode.cpp:74,108,126,162) and its
+    // own scheduler relies on that: a worker gets a pointer into the caller's contiguous buffer, so block k's look-ahead
+    // sees block k+1 (tsq_threads.cpp:109).  The same bytes are taken here, as far as they are readable: the copy goes
+    // through process_vm_readv on this process, which stops at an unmapped page instead of faulting; what cannot be
+    // read is seen as zeros (the canonical conditions after the last block).
+    size_t halo = 0;
+    if (!getenv("TSQ_AMD_ENCODE_NO_LOOKAHEAD")) {
+        struct iovec to = { l.h_in + inputSize, kHalo }, from = { inputBlock + inputSize, kHalo };
+        ssize_t got = process_vm_readv(getpid(), &to, 1, &from, 1, 0);
+        if (got > 0) halo = (size_t)got;
+    }
+    if (hipMemcpyAsync(l.d_in, l.h_in, inputSize + halo, hipMemcpyHostToDevice, s) != hipSuccess) return;
     (void)hipMemsetAsync(l.dev->d_status, 0, sizeof(int32_t), s);
-    if (l.dev->launch_encode(l.d_in, inputSize, inputSize, withExtensions, l.dev->d_status, s) != TSQA_OK) return;
+    if (l.dev->launch_encode(l.d_in, inputSize, inputSize + halo, withExtensions, l.dev->d_status, s) != TSQA_OK) return;
     *l.h_size = 0;
     (void)hipMemcpyAsync(l.h_size, l.dev->sizes, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     (void)hipMemcpyAsync(l.h_status, l.dev->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s);

@@ -1,8 +1,8 @@
 // tsq_dec_ring.cuh -- wave-parallel block decoder with an LDS history ring (kernel variant 0).
 //
-// Same phase structure as tsq_dec_fast.cuh (speculative group parse at every offset, pointer
-// doubling, chain follow, group scan, symbol records, pointer-jumping copy resolution), with the
-// two things its profile asked for:
+// Phase structure: speculative group parse at every offset, pointer doubling, chain follow, group
+// scan, symbol records, pointer-jumping copy resolution (the first parallel decoder, now
+// ab/tsq_dec_fast.cuh, had the same phases), with the two things that one's profile asked for:
 //   * the last 64 KiB of output live in an LDS ring.  Match sources reach at most 65534 bytes
 //     before the start of their symbol pair (tsq_decode.cpp:73), i.e. never further back than the
 //     ring, so history bytes are read from LDS at byte granularity instead of gathering 16 bytes
@@ -17,7 +17,7 @@
 #include <type_traits>
 
 #include "tsq_common.cuh"
-#include "tsq_dec_fast.cuh"      // DecSym, TSQD_* stats macros, g_dec_stats
+#include "tsq_dec_common.cuh"
 
 namespace tsq {
 

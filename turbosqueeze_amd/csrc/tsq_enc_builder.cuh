@@ -1,0 +1,183 @@
+// tsq_enc_builder.cuh -- the stream BUILDER wave of the staged encoder and its batch layout.
+//
+// The parser hands over, through a single-producer/single-consumer queue in LDS, one item per hazard-free
+// segment of a tile (visited mask + which visited lanes are matches + per-lane candidate|nibble words + the parse
+// state at segment entry) or per explicitly pushed symbol.  The builder derives the symbols in parallel -- matches =
+// visited match lanes, literals = 16-byte chunks of visited literal runs, symbol indices by popcount, pair origin of
+// an odd symbol = start of the previous one -- and every 64 symbols lays the stream out (emit_batch): control bytes
+// from a ballot, size bytes from a shuffle, payload offsets from a prefix sum (tsq_encode.cpp:57-59,94-95,103-118,
+// 152-159).  The never-filled trailing control/size bytes get the reference's stale values (tsq_encode.cpp:176-188).
+#pragma once
+
+#include "tsq_common.cuh"
+#include "tsq_enc_util.cuh"
+
+namespace tsq {
+
+// Lay out and store the `cnt` (<= 64) symbols held one per lane in `rec`, starting at output
+// position j0 which is the start of a group of 8 (tsq_encode.cpp:57-59,94-95: control byte, then per
+// pair a size byte and the two payloads).  Returns the output position after the last payload.
+// lit_out / lit_src report the last literal chunk of the batch (for the never-filled trailing
+// bytes); lit_out == 0xFFFFFFFF when the batch holds no literal.  Not inlined: it runs once per
+// 64 symbols and must not bloat the walk loop; the caller re-uniforms the results.
+struct EmitResult { uint32_t end, lit_out, lit_src; };
+__device__ __noinline__ EmitResult emit_batch(uint32_t rec, uint32_t cnt, uint32_t j0, uint8_t* out, const uint8_t* src,
+                                              uint64_t avail, uint32_t lane)
+{
+    uint32_t lit_out = 0xFFFFFFFFu, lit_src = 0;
+    const bool live = lane < cnt;
+    const uint32_t lit = live ? rec >> 31 : 1u;                   // padding symbols count as literals (tsq_encode.cpp:180)
+    const uint32_t nib = live ? (lit ? (rec >> 22) & 15u : (rec >> 16) & 15u) : 0u;
+    const uint32_t pay = live ? (lit ? nib + 1u : 2u) : 0u;
+    const uint32_t extra = live ? (uint32_t)((lane & 7u) == 0u) + (uint32_t)((lane & 1u) == 0u) : 0u;
+    uint32_t incl = pay + extra;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) { uint32_t up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+    const uint32_t at = j0 + incl - (pay + extra);                // where this symbol's control/size/payload region starts
+    const uint32_t end = j0 + rdlane(incl, 63);
+
+    const uint64_t lits = __ballot(lit != 0u);
+    if (live && (lane & 7u) == 0u) {                               // control byte: first symbol of the group in bit 7
+        uint32_t bits = (uint32_t)(lits >> lane) & 0xFFu;
+        bits = __builtin_bitreverse32(bits) >> 24;
+        out[at] = (uint8_t)bits;
+    }
+    const uint32_t nib_next = __shfl_down(nib, 1);
+    if (live && (lane & 1u) == 0u) out[at + (uint32_t)((lane & 7u) == 0u)] = (uint8_t)((nib << 4) | nib_next);
+    const uint32_t pay_at = at + extra;
+    if (live) {
+        if (lit) {
+            const uint32_t pos = rec & 0x3FFFFFu;
+            const uint4 v = ld128z(src, pos, avail);
+            const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (uint32_t t = 0; t < 16; ++t)
+                if (t <= nib) out[pay_at + t] = (uint8_t)(wds[t >> 2] >> (8u * (t & 3u)));
+        } else {
+            const uint16_t off = (uint16_t)rec;
+            __builtin_memcpy(out + pay_at, &off, 2);
+        }
+    }
+    const uint64_t live_lits = lits & below(cnt);
+    if (live_lits) {
+        const uint32_t last = 63u - (uint32_t)__builtin_clzll(live_lits);
+        lit_out = rdlane(pay_at, last);
+        lit_src = rdlane(rec, last) & 0x3FFFFFu;
+    }
+    return EmitResult{end, lit_out, lit_src};
+}
+
+template <class Cfg>
+__device__ __forceinline__ void stream_builder(const uint8_t* src, uint64_t avail, uint8_t* out, lds_u8_t* lds, uint32_t lane,
+                                             uint32_t b, uint32_t* sizes, int32_t* status)
+{
+        volatile lds_u32_t* queue = (volatile lds_u32_t*)(lds + Cfg::off_queue);
+    volatile lds_u32_t* ring = (volatile lds_u32_t*)(lds + Cfg::off_ring);
+    lds_u32_t* ctl = (lds_u32_t*)(lds + Cfg::off_ctl);
+    uint32_t tail = 0, nsym = 0, j0 = 3, lit_out = 0xFFFFFFFFu, lit_src = 0;
+    bool overflow = false;
+
+    auto flush_batch = [&](uint32_t first_index, uint32_t cnt) {
+        if (overflow) return;
+        const uint32_t rec = ring[(first_index + lane) & (Cfg::RING - 1u)];
+        const EmitResult r = emit_batch(rec, cnt, j0, out, src, avail, lane);
+        j0 = uniform(r.end);
+        const uint32_t lo = uniform(r.lit_out);
+        if (lo != 0xFFFFFFFFu) { lit_out = lo; lit_src = uniform(r.lit_src); }
+        if (j0 + 1200u > kSlotSize) overflow = true;
+    };
+
+#ifdef TSQ_STATS
+    unsigned long long st_[32] = {0};
+#endif
+#ifdef TSQ_STATS
+    const unsigned long long begin_ = __builtin_amdgcn_s_memtime();
+#endif
+    for (;;) {
+        if (__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == tail) {
+#ifdef TSQ_STATS
+            const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
+#endif
+            while (__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == tail) __builtin_amdgcn_s_sleep(1);
+#ifdef TSQ_STATS
+            st_[17] += __builtin_amdgcn_s_memtime() - w0_;
+#endif
+        }
+        volatile lds_u32_t* it = queue + (tail % Cfg::Q) * Cfg::ITEM_WORDS;
+        const uint32_t kind = uniform(it[0]);
+        const uint32_t nsym_entry = uniform(it[4]);
+        uint32_t nsym_after = nsym_entry;
+        if (kind == kItemSym) {
+            if (lane == 0) ring[nsym_entry & (Cfg::RING - 1u)] = it[9];
+            nsym_after = nsym_entry + 1u;
+        } else if (kind == kItemSeg) {
+            const uint32_t base = uniform(it[1]);
+            const uint64_t V = (uint64_t)uniform(it[2]) | ((uint64_t)uniform(it[3]) << 32);
+            const uint32_t origin_entry = uniform(it[5]);
+            uint32_t lit_from = uniform(it[6]);
+            const uint64_t certain_m = (uint64_t)uniform(it[7]) | ((uint64_t)uniform(it[8]) << 32);
+            const uint32_t lane_word = it[16 + lane];
+            const uint32_t cand0 = lane_word & 0xFFFFFFu, nib = lane_word >> 24;
+            const uint32_t p = base + lane;
+            const uint64_t M = V & certain_m, N = V & ~certain_m;
+            const uint32_t Ls = lsb64(V);
+            uint32_t idx0 = nsym_entry;
+            if (((M >> Ls) & 1ull) && lit_from < base + Ls) {
+                // a literal run ended exactly at the segment boundary: its pending bytes close here
+                if (lane == 0) ring[idx0 & (Cfg::RING - 1u)] = rec_literal(lit_from, base + Ls - lit_from);
+                idx0++;
+                lit_from = base + Ls;
+            }
+            // the pair origin seen by an odd first symbol: the parser's origin, unless the literal above was symbol idx0-1
+            const uint32_t first_prev_start = (idx0 != nsym_entry) ? uniform(it[6]) : origin_entry;
+            const uint32_t len_first = ((N >> Ls) & 1ull) ? ones_from(N, Ls) : 0u;
+            const uint64_t startN = N & ~(N << 1);
+            const bool isM = (M >> lane) & 1ull, isN = (N >> lane) & 1ull;
+            const bool in_first = lane >= Ls && lane < Ls + len_first;
+            const uint64_t sb = startN & below(lane + 1u);
+            const uint32_t rs_lane = sb ? msb64(sb) : 0u;
+            const uint32_t rs_pos = in_first ? lit_from : base + rs_lane;
+            const uint32_t off = p - rs_pos;
+            const bool next_isM = lane < 63u && ((M >> (lane + 1u)) & 1ull);
+            const bool ownerN = isN && ((off & 15u) == 15u || next_isM);
+            const bool sym = isM || ownerN;
+            const uint64_t SS = __ballot(sym);
+            const uint64_t before = SS & below(lane);
+            const uint32_t idx = idx0 + (uint32_t)__builtin_popcountll(before);
+            const uint32_t sym_start = isM ? p : p - (off & 15u);
+            const uint32_t prev_start_v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((before ? msb64(before) : 0u) << 2), (int)sym_start);
+            const uint32_t pair_origin = (idx & 1u) ? (before ? prev_start_v : first_prev_start) : sym_start;
+            if (sym) ring[idx & (Cfg::RING - 1u)] = isM ? rec_match(pair_origin - cand0, nib) : rec_literal(sym_start, (off & 15u) + 1u);
+            nsym_after = idx0 + (uint32_t)__builtin_popcountll(SS);
+        }
+        // the item is consumed: release the slot before the (long) flush
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tail++;
+        __hip_atomic_store(&ctl[1], tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (kind == kItemEnd) { nsym = nsym_entry; break; }
+        if ((nsym ^ nsym_after) & ~63u) flush_batch((nsym_after & ~63u) - 64u, 64u);
+        nsym = nsym_after;
+    }
+#ifdef TSQ_STATS
+    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[17] = st_[17]; g_enc_stats[18] = __builtin_amdgcn_s_memtime() - begin_; }
+#endif
+
+    if (overflow) { if (lane == 0) { atomicMax(status, kErrOverflow); sizes[b] = 3; } return; }
+    const uint32_t rest = nsym & 63u;
+    if (rest) flush_batch(nsym - rest, rest);
+    auto stale = [&](uint32_t pos) -> uint32_t {
+        const uint32_t d = pos - lit_out;
+        return (lit_out != 0xFFFFFFFFu && d < 16u) ? ldu8z(src, (uint64_t)lit_src + d, avail) : 0u;
+    };
+    uint32_t total = j0;
+    if ((nsym & 7u) == 0u) {
+        if (lane == 0) { out[j0] = (uint8_t)stale(j0); out[j0 + 1] = (uint8_t)stale(j0 + 1); }
+        total = j0 + 2;
+    } else if ((nsym & 1u) == 0u) {
+        if (lane == 0) out[j0] = (uint8_t)(stale(j0) << 4);
+        total = j0 + 1;
+    }
+    if (lane == 0) sizes[b] = total;
+}
+
+}  // namespace tsq

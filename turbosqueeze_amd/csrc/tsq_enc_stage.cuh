@@ -12,7 +12,7 @@
 //   wave 2  ORBIT    the visited set from every possible entry lane of the tile, by pointer doubling.
 //   wave 3  PARSER   the serial part: picks the orbit of the actual entry lane, checks the twins it
 //                    visited, resolves hazards with exact scalar code, keeps the pair state.
-//   wave 4  BUILDER  symbol records and stream layout (tsq_enc_pipe.cuh: pipe_builder).
+//   wave 4  BUILDER  symbol records and stream layout (tsq_enc_builder.cuh: stream_builder).
 //
 // Table lag.  MATCH gathers tile t from a table that holds exactly the visits of tiles <= t-3 (it does
 // the commits itself, in program order), so parser and MATCH overlap over two tiles.  What the table
@@ -24,7 +24,8 @@
 #pragma once
 
 #include "tsq_common.cuh"
-#include "tsq_enc_pipe.cuh"
+#include "tsq_enc_util.cuh"
+#include "tsq_enc_builder.cuh"
 
 namespace tsq {
 
@@ -83,9 +84,14 @@ enum : uint32_t { kAH = 0, kATin = 1, kATp1 = 3, kATp2 = 5, kASpan = 7, kALane =
 #define TSQ_BEGIN() do {} while (0)
 #endif
 
+// Consuming a record: the counter is read first, the record's words after it.  The LDS executes the DS operations of a
+// wavefront in program order (see stage_publish), so only the compiler has to be kept from hoisting record loads above
+// the counter load: the barrier below is the acquire half of the handshake at compiler level.
 __device__ __forceinline__ bool stage_ready(lds_u32_t* ctl, uint32_t word, uint32_t need)
 {
-    return uniform(__hip_atomic_load(&ctl[word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= need;
+    const uint32_t seen = uniform(__hip_atomic_load(&ctl[word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    asm volatile("" ::: "memory");
+    return seen >= need;
 }
 __device__ __forceinline__ bool stage_spin(lds_u32_t* ctl, uint32_t word, uint32_t need)
 {
@@ -780,16 +786,19 @@ __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail,
 }
 
 template <bool EXT, bool WINDOW>
-__global__ __launch_bounds__(320) void enc_stage_kernel(const uint8_t* __restrict__ in, uint64_t n_total, uint64_t readable,
+__global__ __launch_bounds__(320) void enc_stage_kernel(const uint8_t* __restrict__ in, uint64_t n_total, uint64_t readable, uint64_t stride,
                                                         uint8_t* __restrict__ slots, uint32_t* __restrict__ sizes,
                                                         uint16_t* __restrict__ tables, int32_t* __restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t stage_lds[];
     const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u;
     const uint32_t role = uniform(threadIdx.x >> 6);
-    const uint64_t start = (uint64_t)b << kBlockBits;
+    // block b of the launch lies at in + b * stride (stride = 4 MiB: one contiguous buffer; larger: a shard's blocks, each
+    // followed by its own look-ahead bytes); its length follows from the virtual total n_total = (blocks - 1) * 4 MiB + last
+    const uint64_t start = (uint64_t)b * stride;
     const uint64_t avail = readable - start;
-    const uint32_t n = n_total - start < kBlockSize ? (uint32_t)(n_total - start) : kBlockSize;
+    const uint64_t vstart = (uint64_t)b << kBlockBits;
+    const uint32_t n = n_total - vstart < kBlockSize ? (uint32_t)(n_total - vstart) : kBlockSize;
     const uint8_t* src = in + start;
     uint8_t* out = slots + (size_t)b * kSlotSize;
     uint16_t* table = tables + (size_t)b * kHashEntries;
@@ -812,7 +821,7 @@ __global__ __launch_bounds__(320) void enc_stage_kernel(const uint8_t* __restric
     else if (role == 1) stage_scan<WINDOW>(src, avail, n, lds3, lane);
     else if (role == 2) stage_match<EXT, WINDOW>(src, avail, n, table, lds3, lane);
     else if (role == 3) stage_orbit<EXT>(n, lds3, lane);
-    else pipe_builder<StageCfg>(src, avail, out, lds3, lane, b, sizes, status);
+    else stream_builder<StageCfg>(src, avail, out, lds3, lane, b, sizes, status);
 }
 
 }  // namespace tsq

@@ -20,22 +20,30 @@ struct tsqa_ctx {
     uint32_t* sizes = nullptr;         // n_blocks stream sizes
     uint64_t* frame_at = nullptr;      // n_blocks + 1 frame offsets in the container
     tsq::FrameInfo* frames = nullptr;  // n_blocks frame descriptors (decode)
-    uint16_t* tables = nullptr;        // n_blocks x 2^17 u16 (serial encoder variant only)
+    uint16_t* tables = nullptr;        // n_blocks x 2^17 u16 position tables of the encoders
     size_t cap_blocks = 0, cap_tables = 0;
     uint64_t* d_size = nullptr;        // result words of the synchronous entry points
     int32_t* d_status = nullptr;
     int enc_variant = 0, dec_variant = 0;
     char err[256] = {0};
-    // optional kernel timing (tsqa_profile_*): event pairs around the dominant kernels
+    // optional timing (tsqa_profile_*): HIP event pairs on the launch stream, taken from a pool made when profiling is
+    // switched on (nothing is created or destroyed between the events).  Kinds: 0 encode kernel, 1 decode kernel,
+    // 2 whole compress call (encode + container pack), 3 whole decompress call (frame walk + decode).
+    static constexpr int kProfKinds = 4, kProfPairs = 256;
     bool profiling = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> enc_events, dec_events;
-    hipEvent_t prof_begin(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, hipStream_t s);
-    void prof_end(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, hipStream_t s);
+    std::vector<hipEvent_t> prof_pool;                     // kProfKinds * kProfPairs * 2 events
+    uint32_t prof_used[kProfKinds] = {0, 0, 0, 0};
+    bool prof_begin(int kind, hipStream_t s);
+    void prof_end(int kind, hipStream_t s);
 
     void set_error(const char* fmt, ...) __attribute__((format(printf, 2, 3)));
     int reserve(size_t n_blocks, bool want_tables);
     // `readable` >= n: bytes of d_in that may be read (look-ahead halo); zeros are seen beyond it
     int launch_encode(const void* d_in, size_t n, size_t readable, uint32_t ext, int32_t* status, hipStream_t s);
+    // general form: block b at d_in + b * stride, streams to slots_out[b * TSQ_OUTPUT_SZ], sizes to sizes_out[b]
+    int launch_encode_to(const void* d_in, size_t n, size_t readable, size_t stride, uint32_t ext, uint8_t* slots_out,
+                         uint32_t* sizes_out, int32_t* status, hipStream_t s);
+    int launch_decode_frames(const void* d_streams, const tsq::FrameInfo* d_frames, uint32_t n_blocks, void* d_out, int32_t* status, hipStream_t s);
     int launch_pack(size_t n, uint32_t ext, void* d_out, size_t out_cap, uint64_t* d_out_size, int32_t* status, hipStream_t s);
     int launch_decode(const void* d_container, uint32_t n_blocks, void* d_out, int32_t* status, hipStream_t s);
 };

@@ -1,0 +1,129 @@
+// tsq_launch.cuh -- kernel selection and launch for the device context.
+//
+// The product library carries three kernel families: the five-wave staged encoder (tsq_enc_stage.cuh, standard and lean
+// layouts, with and without extensions), the ring decoder (tsq_dec_ring.cuh, standard and lean) and the serial
+// correctness baselines (tsq_serial.cuh, variant 1).  The superseded generations (ab/: variants 2-5) are compiled only
+// into the A/B library (`make ab`, -DTSQ_AB_VARIANTS), which tests/test_gpu_parity.py holds against the same oracle.
+#pragma once
+
+#include <atomic>
+
+#include "tsq_common.cuh"
+#include "tsq_emit.cuh"
+#include "tsq_internal.h"
+#include "tsq_serial.cuh"
+#include "tsq_dec_ring.cuh"
+#include "tsq_enc_stage.cuh"
+#ifdef TSQ_AB_VARIANTS
+#include "ab/tsq_dec_fast.cuh"
+#include "ab/tsq_enc_fast.cuh"
+#include "ab/tsq_enc_orbit.cuh"
+#include "ab/tsq_enc_pipe.cuh"
+#include "ab/tsq_enc_tile.cuh"
+#endif
+
+namespace tsq {
+
+// the dynamic-LDS limit is a per-device attribute of a kernel function: raised once per device the process uses
+template <size_t N>
+inline int raise_lds_limit(tsqa_ctx* c, std::atomic<uint64_t>& done, const void* const (&fns)[N], const uint32_t (&bytes)[N])
+{
+    const uint64_t dev_bit = 1ull << (c->device & 63);
+    if (done.load() & dev_bit) return 0;
+    for (size_t k = 0; k < N; ++k)
+        if (hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes[k]) != hipSuccess) {
+            c->set_error("cannot reserve %u B of LDS", bytes[k]);
+            return TSQA_ERR_HIP;
+        }
+    done.fetch_or(dev_bit);
+    return 0;
+}
+
+#define TSQ_LAUNCH_ENC(KERNEL, THREADS, LDS)                                                                                        \
+    hipLaunchKernelGGL((KERNEL), dim3(nb), dim3(THREADS), (LDS), s, in, (uint64_t)n, (uint64_t)readable, (uint64_t)stride, slots, sizes, c->tables, status)
+
+// Encode nb = ceil(n / 4 MiB) blocks; block b is read at in + b * stride, streams land in slots[b], sizes in sizes[b].
+inline int launch_encode_kernels(tsqa_ctx* c, const uint8_t* in, size_t n, size_t readable, size_t stride, uint32_t ext,
+                                 uint8_t* slots, uint32_t* sizes, int32_t* status, hipStream_t s)
+{
+    const uint32_t nb = (uint32_t)((n + kBlockSize - 1) / kBlockSize);
+    static std::atomic<uint64_t> attr_devices{0};
+    {
+        const void* const fns[4] = {reinterpret_cast<const void*>(enc_stage_kernel<true, true>), reinterpret_cast<const void*>(enc_stage_kernel<false, true>),
+                                    reinterpret_cast<const void*>(enc_stage_kernel<true, false>), reinterpret_cast<const void*>(enc_stage_kernel<false, false>)};
+        const uint32_t bytes[4] = {StageCfg::total, StageCfg::total, StageCfg::total_lean, StageCfg::total_lean};
+        if (int rc = raise_lds_limit(c, attr_devices, fns, bytes)) return rc;
+    }
+    const int v = c->enc_variant;
+    if (v == 1) {                       // one lane walks the block: the correctness baseline
+        if (ext) TSQ_LAUNCH_ENC(enc_serial_kernel<true>, 64, 0);
+        else     TSQ_LAUNCH_ENC(enc_serial_kernel<false>, 64, 0);
+        return 0;
+    }
+#ifdef TSQ_AB_VARIANTS
+    if (v >= 2 && v <= 5) {
+        if (stride != kBlockSize) { c->set_error("the A/B encoder variants take contiguous blocks only"); return TSQA_ERR_ARG; }
+        static std::atomic<uint64_t> ab_devices{0};
+        const void* const fns[8] = {reinterpret_cast<const void*>(enc_tile_kernel<true>), reinterpret_cast<const void*>(enc_tile_kernel<false>),
+                                    reinterpret_cast<const void*>(enc_fast_kernel<true>), reinterpret_cast<const void*>(enc_fast_kernel<false>),
+                                    reinterpret_cast<const void*>(enc_orbit_kernel<true>), reinterpret_cast<const void*>(enc_orbit_kernel<false>),
+                                    reinterpret_cast<const void*>(enc_pipe_kernel<true>), reinterpret_cast<const void*>(enc_pipe_kernel<false>)};
+        const uint32_t bytes[8] = {TileCfg::total, TileCfg::total, kEncLds, kEncLds, kOrbLds, kOrbLds, PipeCfg::total, PipeCfg::total};
+        if (int rc = raise_lds_limit(c, ab_devices, fns, bytes)) return rc;
+#define TSQ_LAUNCH_AB(KERNEL, THREADS, LDS) hipLaunchKernelGGL((KERNEL), dim3(nb), dim3(THREADS), (LDS), s, in, (uint64_t)n, (uint64_t)readable, slots, sizes, c->tables, status)
+        if (v == 2) { if (ext) TSQ_LAUNCH_AB(enc_fast_kernel<true>, 64, kEncLds); else TSQ_LAUNCH_AB(enc_fast_kernel<false>, 64, kEncLds); }          // windowed scalar walk
+        else if (v == 3) { if (ext) TSQ_LAUNCH_AB(enc_orbit_kernel<true>, 64, kOrbLds); else TSQ_LAUNCH_AB(enc_orbit_kernel<false>, 64, kOrbLds); }   // single-wave orbit
+        else if (v == 4) { if (ext) TSQ_LAUNCH_AB(enc_pipe_kernel<true>, 128, PipeCfg::total); else TSQ_LAUNCH_AB(enc_pipe_kernel<false>, 128, PipeCfg::total); }   // parser + builder
+        else { if (ext) TSQ_LAUNCH_AB(enc_tile_kernel<true>, 192, TileCfg::total); else TSQ_LAUNCH_AB(enc_tile_kernel<false>, 192, TileCfg::total); }   // front + parser + builder
+#undef TSQ_LAUNCH_AB
+        return 0;
+    }
+#else
+    if (v >= 2 && v <= 5) { c->set_error("kernel variant %d lives in the A/B library only (make ab)", v); return TSQA_ERR_ARG; }
+#endif
+    // five-wave staged pipeline: scan + match + orbit + parser + builder.  More blocks than CUs: the lean layout (no input
+    // window in LDS, candidate bytes from L2) lets two blocks share a CU; each is a little slower, together they are faster.
+    const bool lean = v == 6 || (v == 0 && nb > (uint32_t)c->n_cus);
+    if (lean) {
+        if (ext) TSQ_LAUNCH_ENC((enc_stage_kernel<true, false>), 320, StageCfg::total_lean);
+        else     TSQ_LAUNCH_ENC((enc_stage_kernel<false, false>), 320, StageCfg::total_lean);
+    } else {
+        if (ext) TSQ_LAUNCH_ENC((enc_stage_kernel<true, true>), 320, StageCfg::total);
+        else     TSQ_LAUNCH_ENC((enc_stage_kernel<false, true>), 320, StageCfg::total);
+    }
+    return 0;
+}
+#undef TSQ_LAUNCH_ENC
+
+inline int launch_decode_kernels(tsqa_ctx* c, const uint8_t* container, const FrameInfo* frames, uint32_t n_blocks, uint8_t* out,
+                                 int32_t* status, hipStream_t s)
+{
+    static std::atomic<uint64_t> attr_devices{0};
+    {
+        const void* const fns[2] = {reinterpret_cast<const void*>(dec_ring_kernel<true>), reinterpret_cast<const void*>(dec_ring_kernel<false>)};
+        const uint32_t bytes[2] = {RingLds::total, LeanLds::total};
+        if (int rc = raise_lds_limit(c, attr_devices, fns, bytes)) return rc;
+    }
+    const int v = c->dec_variant;
+    if (v == 1) { hipLaunchKernelGGL(dec_serial_kernel, dim3(n_blocks), dim3(64), 0, s, container, frames, out, status); return 0; }
+#ifdef TSQ_AB_VARIANTS
+    if (v == 2) {                       // the first parallel decoder (history gathered from L2)
+        static std::atomic<uint64_t> ab_devices{0};
+        const void* const fns[1] = {reinterpret_cast<const void*>(dec_fast_kernel)};
+        const uint32_t bytes[1] = {DecLds::total};
+        if (int rc = raise_lds_limit(c, ab_devices, fns, bytes)) return rc;
+        hipLaunchKernelGGL(dec_fast_kernel, dim3(n_blocks), dim3(DecCfg::T), DecLds::total, s, container, frames, out, status);
+        return 0;
+    }
+#else
+    if (v == 2) { c->set_error("kernel variant 2 lives in the A/B library only (make ab)"); return TSQA_ERR_ARG; }
+#endif
+    // more blocks than CUs: the lean layout lets two blocks share a CU (variant 6 forces it, 7 never uses it)
+    if (v == 6 || (v == 0 && n_blocks > (uint32_t)c->n_cus))
+        hipLaunchKernelGGL(dec_ring_kernel<false>, dim3(n_blocks), dim3(LeanCfg::T), LeanLds::total, s, container, frames, out, status);
+    else
+        hipLaunchKernelGGL(dec_ring_kernel<true>, dim3(n_blocks), dim3(RingCfg::T), RingLds::total, s, container, frames, out, status);
+    return 0;
+}
+
+}  // namespace tsq

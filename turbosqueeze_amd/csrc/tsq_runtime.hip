@@ -10,7 +10,7 @@
 #include "tsq_common.cuh"
 #include "tsq_container.cuh"
 #include "tsq_serial.cuh"
-#include "tsq_fast.cuh"
+#include "tsq_launch.cuh"
 
 #include <cstdarg>
 #include <cstdio>
@@ -75,6 +75,7 @@ extern "C" void tsqa_destroy(tsqa_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    for (hipEvent_t e : c->prof_pool) if (e) (void)hipEventDestroy(e);
     (void)hipFree(c->slots); (void)hipFree(c->tables); (void)hipFree(c->sizes); (void)hipFree(c->frame_at);
     (void)hipFree(c->frames); (void)hipFree(c->d_size); (void)hipFree(c->d_status);
     delete c;
@@ -86,7 +87,7 @@ extern "C" void tsqa_set_kernel_variant(tsqa_ctx* c, int ev, int dv) { if (c) { 
 
 // Scratch in HBM, grown on demand and kept: slots (TSQ_OUTPUT_SZ per block, the reference's
 // per-block output buffer, tsq_context.cpp:89-143), per-block sizes, frame offsets, frame
-// descriptors and -- for the serial encoder variant only -- one 256 KiB table per block.
+// descriptors and one 256 KiB position table per block for the encoders (want_tables).
 int tsqa_ctx::reserve(size_t n_blocks, bool want_tables)
 {
     (void)hipSetDevice(device);
@@ -111,36 +112,42 @@ int tsqa_ctx::reserve(size_t n_blocks, bool want_tables)
 }
 
 // ---- kernel timing ----
-hipEvent_t tsqa_ctx::prof_begin(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, hipStream_t s)
+bool tsqa_ctx::prof_begin(int kind, hipStream_t s)
 {
-    if (!profiling || v.size() >= 256) return nullptr;
-    hipEvent_t a = nullptr, b = nullptr;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return nullptr;
-    v.emplace_back(a, b);
-    (void)hipEventRecord(a, s);
-    return a;
+    if (!profiling || prof_used[kind] >= (uint32_t)kProfPairs) return false;
+    const size_t at = ((size_t)kind * kProfPairs + prof_used[kind]) * 2;
+    prof_used[kind]++;
+    (void)hipEventRecord(prof_pool[at], s);
+    return true;
 }
-void tsqa_ctx::prof_end(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, hipStream_t s)
+void tsqa_ctx::prof_end(int kind, hipStream_t s)
 {
-    if (!v.empty()) (void)hipEventRecord(v.back().second, s);
+    const size_t at = ((size_t)kind * kProfPairs + prof_used[kind] - 1) * 2 + 1;
+    (void)hipEventRecord(prof_pool[at], s);
 }
 
 extern "C" int tsqa_profile_enable(tsqa_ctx* c, int on)
 {
     if (!c) return TSQA_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    if (on && c->prof_pool.empty()) {
+        c->prof_pool.resize((size_t)tsqa_ctx::kProfKinds * tsqa_ctx::kProfPairs * 2, nullptr);
+        for (auto& e : c->prof_pool)
+            if (hipEventCreate(&e) != hipSuccess) { c->set_error("hipEventCreate failed"); return TSQA_ERR_HIP; }
+    }
     c->profiling = on != 0;
     return TSQA_OK;
 }
 
-static void drain_events(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, double* ms, uint32_t* count)
+static void drain_events(tsqa_ctx* c, int kind, double* ms, uint32_t* count)
 {
     double sum = 0; uint32_t n = 0;
-    for (auto& p : v) {
+    for (uint32_t k = 0; k < c->prof_used[kind]; ++k) {
+        const size_t at = ((size_t)kind * tsqa_ctx::kProfPairs + k) * 2;
         float t = 0;
-        if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) { sum += t; n++; }
-        (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second);
+        if (hipEventSynchronize(c->prof_pool[at + 1]) == hipSuccess && hipEventElapsedTime(&t, c->prof_pool[at], c->prof_pool[at + 1]) == hipSuccess) { sum += t; n++; }
     }
-    v.clear();
+    c->prof_used[kind] = 0;
     if (ms) *ms = sum;
     if (count) *count = n;
 }
@@ -149,31 +156,43 @@ extern "C" int tsqa_profile_read(tsqa_ctx* c, double* enc_ms, uint32_t* enc_n, d
 {
     if (!c) return TSQA_ERR_ARG;
     (void)hipSetDevice(c->device);
-    drain_events(c->enc_events, enc_ms, enc_n);
-    drain_events(c->dec_events, dec_ms, dec_n);
+    if (c->prof_pool.empty()) { if (enc_ms) *enc_ms = 0; if (enc_n) *enc_n = 0; if (dec_ms) *dec_ms = 0; if (dec_n) *dec_n = 0; return TSQA_OK; }
+    drain_events(c, 0, enc_ms, enc_n);
+    drain_events(c, 1, dec_ms, dec_n);
     return TSQA_OK;
 }
 
-// ---- internal launches (also used by the reference-API layer in tsq_compat.cpp) ----
+extern "C" int tsqa_profile_read_calls(tsqa_ctx* c, double* comp_ms, uint32_t* comp_n, double* decomp_ms, uint32_t* decomp_n)
+{
+    if (!c) return TSQA_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    if (c->prof_pool.empty()) { if (comp_ms) *comp_ms = 0; if (comp_n) *comp_n = 0; if (decomp_ms) *decomp_ms = 0; if (decomp_n) *decomp_n = 0; return TSQA_OK; }
+    drain_events(c, 2, comp_ms, comp_n);
+    drain_events(c, 3, decomp_ms, decomp_n);
+    return TSQA_OK;
+}
+
+// ---- internal launches (also used by the reference-API layer in tsq_compat.hip) ----
+
+int tsqa_ctx::launch_encode_to(const void* d_in, size_t n, size_t readable, size_t stride, uint32_t ext, uint8_t* slots_out,
+                               uint32_t* sizes_out, int32_t* status, hipStream_t s)
+{
+    const uint32_t nb = (uint32_t)tsqa_block_count(n);
+    int rc = reserve(nb, true);
+    if (rc) return rc;
+    const bool timed = prof_begin(0, s);
+    rc = launch_encode_kernels(this, static_cast<const uint8_t*>(d_in), n, readable, stride, ext, slots_out, sizes_out, status, s);
+    if (rc) return rc;
+    if (timed) prof_end(0, s);
+    TSQ_HIP(this, hipGetLastError());
+    return TSQA_OK;
+}
 
 int tsqa_ctx::launch_encode(const void* d_in, size_t n, size_t readable, uint32_t ext, int32_t* status, hipStream_t s)
 {
-    const uint32_t nb = (uint32_t)tsqa_block_count(n);
-    const bool serial = enc_variant == 1;
-    int rc = reserve(nb, serial);
+    int rc = reserve((uint32_t)tsqa_block_count(n), true);
     if (rc) return rc;
-    const uint8_t* in = static_cast<const uint8_t*>(d_in);
-    const bool timed = prof_begin(enc_events, s) != nullptr;
-    if (serial) {
-        if (ext) hipLaunchKernelGGL(enc_serial_kernel<true>, dim3(nb), dim3(64), 0, s, in, (uint64_t)n, (uint64_t)readable, slots, sizes, tables, status);
-        else     hipLaunchKernelGGL(enc_serial_kernel<false>, dim3(nb), dim3(64), 0, s, in, (uint64_t)n, (uint64_t)readable, slots, sizes, tables, status);
-    } else {
-        rc = launch_encode_fast(this, in, n, readable, ext, status, s);
-        if (rc) return rc;
-    }
-    if (timed) prof_end(enc_events, s);
-    TSQ_HIP(this, hipGetLastError());
-    return TSQA_OK;
+    return launch_encode_to(d_in, n, readable, kBlockSize, ext, slots, sizes, status, s);
 }
 
 int tsqa_ctx::launch_pack(size_t n, uint32_t ext, void* d_out, size_t out_cap, uint64_t* d_out_size, int32_t* status, hipStream_t s)
@@ -188,19 +207,19 @@ int tsqa_ctx::launch_pack(size_t n, uint32_t ext, void* d_out, size_t out_cap, u
     return TSQA_OK;
 }
 
-int tsqa_ctx::launch_decode(const void* d_container, uint32_t n_blocks, void* d_out, int32_t* status, hipStream_t s)
+int tsqa_ctx::launch_decode_frames(const void* d_streams, const FrameInfo* d_frames, uint32_t n_blocks, void* d_out, int32_t* status, hipStream_t s)
 {
-    const uint8_t* in = static_cast<const uint8_t*>(d_container);
-    const bool timed = prof_begin(dec_events, s) != nullptr;
-    if (dec_variant == 1) {
-        hipLaunchKernelGGL(dec_serial_kernel, dim3(n_blocks), dim3(64), 0, s, in, frames, static_cast<uint8_t*>(d_out), status);
-    } else {
-        int rc = launch_decode_fast(this, in, n_blocks, static_cast<uint8_t*>(d_out), status, s);
-        if (rc) return rc;
-    }
-    if (timed) prof_end(dec_events, s);
+    const bool timed = prof_begin(1, s);
+    int rc = launch_decode_kernels(this, static_cast<const uint8_t*>(d_streams), d_frames, n_blocks, static_cast<uint8_t*>(d_out), status, s);
+    if (rc) return rc;
+    if (timed) prof_end(1, s);
     TSQ_HIP(this, hipGetLastError());
     return TSQA_OK;
+}
+
+int tsqa_ctx::launch_decode(const void* d_container, uint32_t n_blocks, void* d_out, int32_t* status, hipStream_t s)
+{
+    return launch_decode_frames(d_container, frames, n_blocks, d_out, status, s);
 }
 
 // ---- public device-resident entry points ----
@@ -214,9 +233,12 @@ extern "C" int tsqa_compress_device_async(tsqa_ctx* c, const void* d_in, size_t 
     hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
     (void)hipSetDevice(c->device);
     TSQ_HIP(c, hipMemsetAsync(d_status, 0, sizeof(int32_t), s));
+    const bool timed = c->prof_begin(2, s);
     int rc = c->launch_encode(d_in, n, n, ext, d_status, s);
     if (rc) return rc;
-    return c->launch_pack(n, ext, d_out, out_cap, d_out_size, d_status, s);
+    rc = c->launch_pack(n, ext, d_out, out_cap, d_out_size, d_status, s);
+    if (timed) c->prof_end(2, s);
+    return rc;
 }
 
 static int status_to_rc(tsqa_ctx* c, int32_t st, const char* what)
@@ -251,9 +273,44 @@ extern "C" int tsqa_decompress_device_async(tsqa_ctx* c, const void* d_in, size_
     int rc = c->reserve(n_blocks, false);
     if (rc) return rc;
     TSQ_HIP(c, hipMemsetAsync(d_status, 0, sizeof(int32_t), s));
+    const bool timed = c->prof_begin(3, s);
     hipLaunchKernelGGL(frame_walk_kernel, dim3(1), dim3(64), 0, s, static_cast<const uint8_t*>(d_in), (uint64_t)n, n_blocks,
                        (uint64_t)out_cap, c->frames, d_out_size, d_status);
-    return c->launch_decode(d_in, n_blocks, d_out, d_status, s);
+    rc = c->launch_decode(d_in, n_blocks, d_out, d_status, s);
+    if (timed) c->prof_end(3, s);
+    return rc;
+}
+
+// ---- sharded operation: a device owns some of a job's blocks ----
+
+extern "C" int tsqa_encode_blocks_async(tsqa_ctx* c, const void* d_in, uint32_t n_blocks, size_t stride, uint32_t last_len,
+                                        uint32_t ext, void* d_slots, uint32_t* d_sizes, int32_t* d_status, void* hip_stream)
+{
+    if (!c) return TSQA_ERR_ARG;
+    if (!d_in || !d_slots || !d_sizes || !d_status || n_blocks == 0 || last_len == 0 || last_len > kBlockSize || stride < kBlockSize) {
+        c->set_error("encode_blocks: bad argument");
+        return TSQA_ERR_ARG;
+    }
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    (void)hipSetDevice(c->device);
+    TSQ_HIP(c, hipMemsetAsync(d_status, 0, sizeof(int32_t), s));
+    // the virtual total gives every block but the last 4 MiB; what may be read ends with the last block's look-ahead
+    const size_t n = (size_t)(n_blocks - 1) * kBlockSize + last_len;
+    const size_t tail = stride > kBlockSize ? (stride - kBlockSize < 128 ? stride - kBlockSize : 128) : 0;
+    const size_t readable = (size_t)(n_blocks - 1) * stride + last_len + tail;
+    return c->launch_encode_to(d_in, n, readable, stride, ext, static_cast<uint8_t*>(d_slots), d_sizes, d_status, s);
+}
+
+extern "C" int tsqa_decode_blocks_async(tsqa_ctx* c, const void* d_streams, const tsqa_frame* d_frames, uint32_t n_blocks,
+                                        void* d_out, int32_t* d_status, void* hip_stream)
+{
+    if (!c) return TSQA_ERR_ARG;
+    if (!d_streams || !d_frames || !d_out || !d_status || n_blocks == 0) { c->set_error("decode_blocks: bad argument"); return TSQA_ERR_ARG; }
+    static_assert(sizeof(tsqa_frame) == sizeof(FrameInfo), "public frame descriptor = kernel frame descriptor");
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    (void)hipSetDevice(c->device);
+    TSQ_HIP(c, hipMemsetAsync(d_status, 0, sizeof(int32_t), s));
+    return c->launch_decode_frames(d_streams, reinterpret_cast<const FrameInfo*>(d_frames), n_blocks, d_out, d_status, s);
 }
 
 extern "C" int tsqa_decompress_device(tsqa_ctx* c, const void* d_in, size_t n, void* d_out, size_t out_cap,
@@ -280,6 +337,86 @@ extern "C" int tsqa_decompress_device(tsqa_ctx* c, const void* d_in, size_t n, v
     TSQ_HIP(c, hipStreamSynchronize(s));
     *out_size = (size_t)sz;
     return status_to_rc(c, st, "decompress");
+}
+
+// Host gather / scatter of a shard's frames (what compression_write_worker and decompression_read_worker do with
+// memcpy, tsq_threads.cpp:226-239,513-524): one DMA per owned block between its slot in HBM and its place in the
+// container in host memory.  The three frame bytes are written / skipped here.
+extern "C" int tsqa_frames_to_host_async(tsqa_ctx* c, const void* d_slots, const uint32_t* sizes, const uint64_t* frame_at,
+                                         uint32_t n_blocks, uint32_t ext, void* host_container, void* hip_stream)
+{
+    if (!c) return TSQA_ERR_ARG;
+    if (!d_slots || !sizes || !frame_at || !host_container) { c->set_error("frames_to_host: null pointer"); return TSQA_ERR_ARG; }
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    (void)hipSetDevice(c->device);
+    uint8_t* base = static_cast<uint8_t*>(host_container);
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        if (sizes[b] < 3 || sizes[b] > kSlotSize) { c->set_error("frames_to_host: block %u has size %u", b, sizes[b]); return TSQA_ERR_ARG; }
+        const uint32_t frame = sizes[b] | (ext ? 0x800000u : 0u);                     // tsq_threads.cpp:218-219
+        uint8_t* p = base + frame_at[b];
+        p[0] = (uint8_t)frame; p[1] = (uint8_t)(frame >> 8); p[2] = (uint8_t)(frame >> 16);
+        TSQ_HIP(c, hipMemcpyAsync(p + 3, static_cast<const uint8_t*>(d_slots) + (size_t)b * kSlotSize, sizes[b], hipMemcpyDeviceToHost, s));
+    }
+    return TSQA_OK;
+}
+
+extern "C" int tsqa_frames_from_host_async(tsqa_ctx* c, const void* host_container, const uint64_t* frame_at, const uint32_t* sizes,
+                                           uint32_t n_blocks, void* d_streams, void* hip_stream)
+{
+    if (!c) return TSQA_ERR_ARG;
+    if (!d_streams || !sizes || !frame_at || !host_container) { c->set_error("frames_from_host: null pointer"); return TSQA_ERR_ARG; }
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    (void)hipSetDevice(c->device);
+    const uint8_t* base = static_cast<const uint8_t*>(host_container);
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        if (sizes[b] < 3 || sizes[b] > kSlotSize) { c->set_error("frames_from_host: block %u has size %u", b, sizes[b]); return TSQA_ERR_FORMAT; }
+        TSQ_HIP(c, hipMemcpyAsync(static_cast<uint8_t*>(d_streams) + (size_t)b * kSlotSize, base + frame_at[b] + 3, sizes[b], hipMemcpyHostToDevice, s));
+    }
+    return TSQA_OK;
+}
+
+// ---- the second roofline denominator: what a plain device copy reaches on this GPU ----
+__global__ __launch_bounds__(256) void copy_probe_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t words)
+{
+    const size_t step = (size_t)gridDim.x * 256u;
+    size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    for (; i + 3 * step < words; i += 4 * step) {               // four independent 16-byte loads in flight per lane
+        const uint4 a = src[i], b = src[i + step], c = src[i + 2 * step], d = src[i + 3 * step];
+        dst[i] = a; dst[i + step] = b; dst[i + 2 * step] = c; dst[i + 3 * step] = d;
+    }
+    for (; i < words; i += step) dst[i] = src[i];
+}
+
+extern "C" int tsqa_measure_copy(tsqa_ctx* c, size_t bytes, int reps, double* best_gbps, double* median_gbps)
+{
+    if (!c || bytes < (size_t(1) << 20) || reps < 1 || reps > 64) return TSQA_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    uint4 *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const size_t words = bytes / 16;
+    int rc = TSQA_OK;
+    double rates[64];
+    if (hipMalloc(&a, words * 16) != hipSuccess || hipMalloc(&b, words * 16) != hipSuccess ||
+        hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess ||
+        hipMemsetAsync(a, 0x5a, words * 16, c->stream) != hipSuccess) rc = TSQA_ERR_HIP;
+    const uint32_t grid = (uint32_t)c->n_cus * 8u;
+    for (int r = -1; r < reps && rc == TSQA_OK; ++r) {          // r == -1 warms up
+        (void)hipEventRecord(e0, c->stream);
+        hipLaunchKernelGGL(copy_probe_kernel, dim3(grid), dim3(256), 0, c->stream, a, b, words);
+        (void)hipEventRecord(e1, c->stream);
+        float ms = 0;
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0) { rc = TSQA_ERR_HIP; break; }
+        if (r >= 0) rates[r] = 2.0 * (double)(words * 16) / (ms * 1e-3) / 1e9;    // bytes read + bytes written
+    }
+    if (rc == TSQA_OK) {
+        for (int i = 1; i < reps; ++i) for (int j = i; j > 0 && rates[j] < rates[j - 1]; --j) { double t = rates[j]; rates[j] = rates[j - 1]; rates[j - 1] = t; }
+        if (best_gbps) *best_gbps = rates[reps - 1];
+        if (median_gbps) *median_gbps = rates[reps / 2];
+    } else c->set_error("copy probe failed");
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(a); (void)hipFree(b);
+    return rc;
 }
 
 #ifdef TSQ_STATS

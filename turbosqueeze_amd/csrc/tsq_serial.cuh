@@ -12,14 +12,15 @@ namespace tsq {
 // Encoder (tsq_encode.cpp:48-189 no-ext, :192-342 ext), hash table in HBM (256 KiB per block).
 // ---------------------------------------------------------------------------------------------
 template <bool EXT>
-__global__ __launch_bounds__(64) void enc_serial_kernel(const uint8_t* __restrict__ in, uint64_t n_total, uint64_t readable,
+__global__ __launch_bounds__(64) void enc_serial_kernel(const uint8_t* __restrict__ in, uint64_t n_total, uint64_t readable, uint64_t stride,
                                                         uint8_t* __restrict__ slots, uint32_t* __restrict__ sizes,
                                                         uint16_t* __restrict__ tables, int32_t* __restrict__ status)
 {
     const uint32_t b = blockIdx.x, lane = threadIdx.x;
-    const uint64_t start = (uint64_t)b << kBlockBits;
+    const uint64_t start = (uint64_t)b * stride;  // (see enc_stage_kernel: contiguous blocks or a shard's blocks with their look-ahead)
     const uint64_t avail = readable - start;      // bytes that may be read from src; zeros beyond
-    const uint32_t n = n_total - start < kBlockSize ? (uint32_t)(n_total - start) : kBlockSize;
+    const uint64_t vstart = (uint64_t)b << kBlockBits;
+    const uint32_t n = n_total - vstart < kBlockSize ? (uint32_t)(n_total - vstart) : kBlockSize;
     const uint8_t* src = in + start;
     uint8_t* out = slots + (size_t)b * kSlotSize;
     uint16_t* table = tables + (size_t)b * kHashEntries;

@@ -4,7 +4,13 @@ Blocks are independent: block b goes to rank b % world (the reference's block i 
 i % num_cores, tsq_threads.cpp:71,463).  Each rank returns (block index, ext, stream bytes); the
 gatherer lays frames out in block order, which is what compression_write_worker does
 (tsq_threads.cpp:192-275).  No collective is needed on the data path; gather_streams() uses one
-gather_object so that rank 0 can write the file.  Pure host logic (no device code)."""
+gather_object so that rank 0 can write the file.  The first half of this file is pure host logic (no device code).
+
+The second half is the one-process-per-GPU form of the same thing: `ShardLayout` (which blocks a rank owns
+and how they lie in its HBM), `HostContainer` (one container in host memory shared by the ranks of a node --
+every rank DMAs its frames straight to their final place, so the "gather" is the prefix sum of the sizes and
+nothing else) and `ShardedCodec` (encode owned blocks -> all-gather of the u32 sizes -> frames to the host
+container; frame walk -> owned frames to HBM -> decode).  The only collective is that all-gather of sizes."""
 from __future__ import annotations
 
 from typing import Dict, Iterable, List, Tuple
@@ -85,3 +91,252 @@ def gather_streams(local: Dict[int, Tuple[int, bytes]], rank: int, world: int, d
     for p in parts:
         merged.update(p)
     return merged
+
+
+# ---------------------------------------------------------------------------------------------
+# One process per GPU
+# ---------------------------------------------------------------------------------------------
+HALO = 128
+OUTPUT_SZ = BLOCK_SZ + (BLOCK_SZ >> 2)
+
+
+class ShardLayout:
+    """Block b of an n_total-byte job belongs to rank b % world.  In a rank's memory its blocks lie back to
+    back, each IMMEDIATELY followed by its 128 look-ahead bytes (what tsqa_encode_blocks_async expects):
+    stride = BLOCK_SZ + HALO; decoded blocks lie back to back at stride BLOCK_SZ."""
+
+    def __init__(self, n_total: int, rank: int, world: int):
+        self.n_total, self.rank, self.world = n_total, rank, world
+        self.nb = block_count(n_total)
+        self.blocks = rank_blocks(self.nb, rank, world)
+        self.stride = BLOCK_SZ + HALO
+        self.lengths = [block_extent(b, n_total)[1] for b in self.blocks]
+        self.last_len = self.lengths[-1] if self.lengths else 0
+        if any(l != BLOCK_SZ for l in self.lengths[:-1]):
+            raise ValueError("only a rank's last block may be short")
+        self.max_blocks = (self.nb + world - 1) // world          # the most blocks any rank owns
+
+    @property
+    def n_local(self) -> int:
+        return len(self.blocks)
+
+    @property
+    def shard_bytes(self) -> int:
+        return sum(self.lengths)
+
+    def pack_input(self, data):
+        """The rank's input in device layout, from the whole job's bytes (a numpy uint8 array)."""
+        import numpy as np
+        out = np.zeros(max(self.n_local, 1) * self.stride, dtype=np.uint8)
+        for k, b in enumerate(self.blocks):
+            start, length = block_extent(b, self.n_total)
+            out[k * self.stride:k * self.stride + length] = data[start:start + length]
+            out[k * self.stride + length:k * self.stride + length + HALO] = np.frombuffer(halo_of(data, b, self.n_total, HALO), dtype=np.uint8)
+        return out
+
+    def expected_output(self, data):
+        """What the rank's decoded blocks must equal (blocks back to back)."""
+        import numpy as np
+        parts = [data[block_extent(b, self.n_total)[0]:block_extent(b, self.n_total)[0] + block_extent(b, self.n_total)[1]] for b in self.blocks]
+        return np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
+
+
+def frame_offsets(all_sizes):
+    """Container offset of every block's frame bytes: 16 + sum over earlier blocks of (3 + size)
+    (tsq_threads.cpp:226-239).  -> (uint64 array of nb offsets, container size)."""
+    import numpy as np
+    sizes = np.asarray(all_sizes, dtype=np.uint64)
+    ends = 16 + np.cumsum(sizes + 3, dtype=np.uint64)
+    at = np.concatenate([np.array([16], dtype=np.uint64), ends[:-1]]) if len(sizes) else np.zeros(0, dtype=np.uint64)
+    return at, int(ends[-1]) if len(sizes) else 16
+
+
+def walk_frames(container, limit: int):
+    """The serial frame walk of a container in host memory (tsq_threads.cpp:513-524) over a numpy uint8 view.
+    -> (total, frame_at uint64[nb], sizes uint32[nb], ext uint32[nb], out_len uint32[nb]); raises ValueError."""
+    import numpy as np
+    if limit < 16 or bytes(container[:4]) != b"TSQ1":
+        raise ValueError("bad magic")
+    nb = int.from_bytes(bytes(container[4:8]), "little")
+    total = int.from_bytes(bytes(container[8:16]), "little")
+    if nb == 0 or nb > (limit - 16) // 6:
+        raise ValueError("bad block count")
+    frame_at = np.zeros(nb, dtype=np.uint64)
+    sizes = np.zeros(nb, dtype=np.uint32)
+    ext = np.zeros(nb, dtype=np.uint32)
+    out_len = np.zeros(nb, dtype=np.uint32)
+    at = 16
+    for b in range(nb):
+        if at + 6 > limit:
+            raise ValueError("truncated")
+        h = bytes(container[at:at + 6])
+        frame = h[0] | h[1] << 8 | h[2] << 16
+        ln = frame & 0x7FFFFF
+        if ln < 3 or ln > OUTPUT_SZ or at + 3 + ln > limit:
+            raise ValueError("bad frame")
+        frame_at[b], sizes[b], ext[b] = at, ln, frame >> 23
+        out_len[b] = h[3] | h[4] << 8 | h[5] << 16
+        if out_len[b] > BLOCK_SZ:
+            raise ValueError("bad block size")
+        at += 3 + ln
+    if int(out_len.sum()) != total:
+        raise ValueError("sizes do not add up")
+    return total, frame_at, sizes, ext, out_len
+
+
+class HostContainer:
+    """One buffer in host memory shared by the ranks of a node (a file in /dev/shm mapped by every rank;
+    hipHostRegister'ed where a GPU is present so that the DMAs run at full speed)."""
+
+    def __init__(self, name: str, size: int, create: bool):
+        import mmap
+        import os
+        self.path = os.path.join("/dev/shm", name)
+        self.size = size
+        self.created = create
+        flags = os.O_RDWR | (os.O_CREAT | os.O_TRUNC if create else 0)
+        fd = os.open(self.path, flags, 0o600)
+        try:
+            if create:
+                os.ftruncate(fd, size)
+            self.map = mmap.mmap(fd, size)
+        finally:
+            os.close(fd)
+        import numpy as np
+        self.array = np.frombuffer(self.map, dtype=np.uint8)
+        self.ptr = self.array.ctypes.data
+        self.registered = False
+
+    def register(self):
+        import torch
+        rc = torch.cuda.cudart().cudaHostRegister(self.ptr, self.size, 0)
+        if int(rc) != 0:
+            raise RuntimeError(f"hipHostRegister failed: {rc}")
+        self.registered = True
+
+    def close(self):
+        import os
+        if self.registered:
+            import torch
+            torch.cuda.cudart().cudaHostUnregister(self.ptr)
+            self.registered = False
+        self.array = None
+        try:
+            self.map.close()
+        except BufferError:
+            pass
+        if self.created:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
+
+
+class DeviceBlocks:
+    """The per-block device operations ShardedCodec needs, over tsqa_*_blocks_async (one GPU)."""
+
+    def __init__(self, codec):
+        import torch
+        self.codec, self.torch, self.device = codec, torch, codec.device
+
+    def alloc(self, n_local: int):
+        t = self.torch
+        self.slots = t.empty(max(n_local, 1) * OUTPUT_SZ, dtype=t.uint8, device=self.device)
+        self.sizes = t.zeros(max(n_local, 1), dtype=t.int32, device=self.device)
+
+    def encode(self, d_in, n_local, stride, last_len, ext):
+        self.codec.encode_blocks_async(d_in, n_local, stride, last_len, ext, self.slots, self.sizes)
+
+    def sizes_tensor(self):
+        return self.sizes
+
+    def frames_to_host(self, sizes, frame_at, ext, host):
+        self.codec.frames_to_host_async(self.slots, sizes, frame_at, ext, host.ptr)
+
+    def frames_from_host(self, host, frame_at, sizes):
+        self.codec.frames_from_host_async(host.ptr, frame_at, sizes, self.slots)
+
+    def decode(self, frames_np, n_local, d_out):
+        t = self.torch
+        d_frames = t.from_numpy(frames_np.view("uint8")).to(self.device, non_blocking=False)
+        self.codec.decode_blocks_async(self.slots, d_frames, n_local, d_out)
+        self._keep = d_frames
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)
+        st = self.codec.status()
+        if st:
+            raise RuntimeError(f"device status {st}")
+
+
+FRAME_DTYPE = [("stream_at", "<u8"), ("out_at", "<u8"), ("stream_len", "<u4"), ("ext", "<u4"), ("out_len", "<u4"), ("pad", "<u4")]
+
+
+class ShardedCodec:
+    """One job, its blocks dealt round-robin over the ranks (block b -> rank b % world), the .tsq container
+    gathered in host memory.  `blocks` does the per-block work (DeviceBlocks on a GPU); everything else here --
+    who owns what, the all-gather of sizes, where every frame goes, the frame walk -- is host logic and is
+    what tests/test_multiprocess_cpu.py drives with world_size 2 on gloo."""
+
+    def __init__(self, layout: ShardLayout, blocks, host: HostContainer, ext: int):
+        self.layout, self.blocks, self.host, self.ext = layout, blocks, host, int(ext)
+        blocks.alloc(layout.n_local)
+
+    def _all_sizes(self):
+        """Every block's stream size, on every rank: ONE all-gather of max_blocks u32 per rank."""
+        import numpy as np
+        lay = self.layout
+        mine = self.blocks.sizes_tensor()
+        if lay.world == 1:
+            local = mine.cpu().numpy().astype(np.uint32)[:lay.n_local]
+            return local.copy()
+        import torch
+        import torch.distributed as dist
+        pad = torch.zeros(lay.max_blocks, dtype=mine.dtype, device=mine.device)
+        pad[:lay.n_local] = mine[:lay.n_local]
+        every = torch.empty(lay.world * lay.max_blocks, dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(every, pad)
+        table = every.cpu().numpy().astype(np.uint32).reshape(lay.world, lay.max_blocks)
+        out = np.zeros(lay.nb, dtype=np.uint32)
+        for r in range(lay.world):
+            owned = rank_blocks(lay.nb, r, lay.world)
+            out[owned] = table[r, :len(owned)]
+        return out
+
+    def compress(self, d_shard) -> int:
+        """Encode the owned blocks and put their frames into the host container.  Returns the container size
+        (the same on every rank).  The caller barriers before anyone reads the container."""
+        import numpy as np
+        lay = self.layout
+        if lay.n_local:
+            self.blocks.encode(d_shard, lay.n_local, lay.stride, lay.last_len, self.ext)
+        sizes = self._all_sizes()
+        frame_at, total = frame_offsets(sizes)
+        if total > self.host.size:
+            raise ValueError("host container too small")
+        if lay.rank == 0:                                         # tsq_threads.cpp:333-335
+            self.host.array[:16] = np.frombuffer(b"TSQ1" + lay.nb.to_bytes(4, "little") + lay.n_total.to_bytes(8, "little"), dtype=np.uint8)
+        if lay.n_local:
+            own = np.asarray(lay.blocks)
+            self.blocks.frames_to_host(np.ascontiguousarray(sizes[own]), np.ascontiguousarray(frame_at[own]), self.ext, self.host)
+        self.blocks.sync()
+        return total
+
+    def decompress(self, container_size: int, d_out) -> int:
+        """Walk the container, bring the owned frames to the device, decode them back to back into d_out.
+        Returns the job's uncompressed size."""
+        import numpy as np
+        lay = self.layout
+        total, frame_at, sizes, ext, out_len = walk_frames(self.host.array, container_size)
+        if len(sizes) != lay.nb or total != lay.n_total:
+            raise ValueError("container does not match the layout")
+        if lay.n_local:
+            own = np.asarray(lay.blocks)
+            self.blocks.frames_from_host(self.host, np.ascontiguousarray(frame_at[own]), np.ascontiguousarray(sizes[own]))
+            fr = np.zeros(lay.n_local, dtype=FRAME_DTYPE)
+            fr["stream_at"] = np.arange(lay.n_local, dtype=np.uint64) * OUTPUT_SZ
+            fr["out_at"] = np.arange(lay.n_local, dtype=np.uint64) * BLOCK_SZ
+            fr["stream_len"], fr["ext"], fr["out_len"] = sizes[own], ext[own], out_len[own]
+            self.blocks.decode(fr, lay.n_local, d_out)
+        self.blocks.sync()
+        return total
