@@ -68,7 +68,16 @@ def cpu_baseline(sample_bytes: int, ext: int, reps: int = 5):
     import turbosqueeze_amd as tsq
     from oracle import pyoracle
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    hw = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores, quota_note = hw, "no cgroup CPU quota"
+    try:                                               # a container may be allowed fewer CPUs than it can see
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            allowed = max(1, int(int(q) / int(period) + 0.5))
+            quota_note = f"cgroup cpu.max allows {allowed} CPUs"
+            cores = min(hw, allowed)
+    except Exception:
+        pass
     host = tsq.synth.text(sample_bytes, seed=1, pad=256)
     orc = pyoracle.Oracle()
     fn = orc.L.tsqo_cpubench2
@@ -94,7 +103,8 @@ def cpu_baseline(sample_bytes: int, ext: int, reps: int = 5):
                 "encode_best": g(min(te)), "decode_best": g(min(td)), "roundtrip_best": g(min(rt)), "rt_median_s": statistics.median(rt)}
 
     ideal = None
-    for threads in sorted({cores, max(cores // 2, 1)}):           # SMT siblings do not always help: keep the better
+    # under / at / over the allowance and every hardware thread (a CFS quota throttles long phases, not short bursts): keep the best
+    for threads in sorted({cores, max(cores // 2, 1), min(2 * cores, hw), hw}):
         r = run(sample_bytes, threads, 0, reps)
         if ideal is None or r["rt_median_s"] < ideal["rt_median_s"]:
             ideal = r
@@ -107,7 +117,7 @@ def cpu_baseline(sample_bytes: int, ext: int, reps: int = 5):
         "value": ideal["roundtrip_GBps"], "unit": "GB/s", "cores": ideal["threads"], "kind": kind,
         "sample": f"{sample_bytes} B of the same enwik9-shaped text; idealised block-parallel pthreads (block i -> thread i % T), "
                   f"threads pinned, pages first-touched by their owner, 1 warm + {reps} timed passes, value = median round trip; "
-                  f"host offers {cores} hardware threads; roundtrip_ok={ideal['ok'] and shaped['ok'] and one['ok']} ratio={ideal['ratio']:.4f}",
+                  f"host shows {hw} hardware threads, {quota_note}; roundtrip_ok={ideal['ok'] and shaped['ok'] and one['ok']} ratio={ideal['ratio']:.4f}",
         "median": ideal["roundtrip_GBps"], "best": ideal["roundtrip_best"],
         "encode_GBps": ideal["encode_GBps"], "decode_GBps": ideal["decode_GBps"],
         "encode_best": ideal["encode_best"], "decode_best": ideal["decode_best"],
@@ -280,8 +290,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             # bounded sample, but never fewer blocks than 2 per host thread (block-parallel CPU code)
-            cores = os.cpu_count() or 1
-            line["cpu_baseline"] = cpu_baseline(min(n, max(args.cpu_sample, 2 * cores * tsq.BLOCK_SZ)), args.ext)
+            line["cpu_baseline"] = cpu_baseline(min(n, args.cpu_sample), args.ext)
     else:
         # ---- one job, blocks dealt round-robin over the ranks, container gathered in host memory
         lay = sharding.ShardLayout(n, rank, world)

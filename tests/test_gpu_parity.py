@@ -240,7 +240,11 @@ def test_tsqencode_lookahead_matches_reference_contract(tsq, oracle):
     last-block stream."""
     n = (1 << 22) + 70000
     host = tsq.synth.text(n, seed=77)
-    host[(1 << 22) - 20:(1 << 22) + 20] = np.resize(np.frombuffer(b"edge", dtype=np.uint8), 40)   # a match across the block edge
+    # a 16-byte phrase early in the block, and again straddling the block edge: 6 bytes inside, 10 in the next block.
+    # With the look-ahead the match at the edge is 16 long; with zeros behind the block it is 6.
+    phrase = np.frombuffer(b"QRSTUVWX12345678", dtype=np.uint8)
+    host[100000:100016] = phrase
+    host[(1 << 22) - 6:(1 << 22) + 10] = phrase
     first, rest = host[:1 << 22].tobytes(), host[1 << 22:].tobytes()
     for ext in (0, 1):
         with_next = tsq.tsq_encode(first, ext, halo=rest[:128])
