@@ -40,7 +40,7 @@ __global__ void k_copy(const uint32_t* src_off, const uint32_t* dst_off, uint8_t
 }
 
 template <int W>
-bool run(const char* name, int threads, bool random_offsets, uint32_t align = 1)
+bool run(const char* name, int threads, bool random_offsets, uint32_t align = 1, bool dense = false)
 {
     std::vector<uint32_t> so(threads), dof(threads);
     uint32_t x = 12345;
@@ -49,6 +49,7 @@ bool run(const char* name, int threads, bool random_offsets, uint32_t align = 1)
         so[t] = random_offsets ? (x >> 8) % (N - 16) : (uint32_t)t * 17u + 3u;      // arbitrary byte phases either way
         dof[t] = (uint32_t)t * 20u + 1u;                                           // distinct, non-overlapping destinations (20 >= 16)
         if (align > 1) { so[t] &= ~(align - 1u); dof[t] = (uint32_t)t * 32u; }
+        if (dense) { so[t] = (uint32_t)t * W; dof[t] = (uint32_t)t * W; }          // consecutive lanes, consecutive items: no bank conflicts
     }
     uint32_t *d_so, *d_do; uint8_t* d_img; unsigned long long* d_cyc;
     hipMalloc(&d_so, threads * 4); hipMalloc(&d_do, threads * 4); hipMalloc(&d_img, 2 * N); hipMalloc(&d_cyc, 8);
@@ -66,7 +67,7 @@ bool run(const char* name, int threads, bool random_offsets, uint32_t align = 1)
     unsigned long long cyc = 0;
     hipMemcpy(&cyc, d_cyc, 8, hipMemcpyDeviceToHost);
     printf("%-6s width %2d  align %2u  threads %4d  %-10s  %s   %.1f cycles per copy per workgroup  (%.2f bytes/cycle/CU)\n", name, W, align, threads,
-           random_offsets ? "random" : "strided", ok ? "CORRECT" : "WRONG", (double)cyc / iters, (double)W * threads * iters / (double)cyc);
+           dense ? "dense" : random_offsets ? "random" : "strided", ok ? "CORRECT" : "WRONG", (double)cyc / iters, (double)W * threads * iters / (double)cyc);
     (void)0;
     hipFree(d_so); hipFree(d_do); hipFree(d_img); hipFree(d_cyc);
     return ok;
@@ -91,6 +92,11 @@ int main()
         ok &= run<16>("b128", 1024, rnd, 8);
         ok &= run<16>("b128", 1024, rnd, 16);
     }
+    ok &= run<1>("b8", 1024, false, 1, true);
+    ok &= run<2>("b16", 1024, false, 2, true);
+    ok &= run<4>("b32", 1024, false, 4, true);
+    ok &= run<8>("b64", 1024, false, 8, true);
+    ok &= run<16>("b128", 1024, false, 16, true);
     printf(ok ? "ALL CORRECT\n" : "FAILURES\n");
     return ok ? 0 : 1;
 }

@@ -13,8 +13,8 @@ sys.path.insert(0, ROOT)
 import turbosqueeze_amd as tsq
 from turbosqueeze_amd import api
 
-api.lib_path = lambda: os.path.join(ROOT, "turbosqueeze_amd", "libturbosqueeze_amd_stats.so")
-api._lib = None
+api.lib_path = lambda ab=False: os.path.join(ROOT, "turbosqueeze_amd", "libturbosqueeze_amd_stats.so")
+api._libs.clear()
 L = api.lib()
 L.tsqa_debug_stats.argtypes = [C.c_void_p, C.c_void_p]
 
@@ -25,6 +25,7 @@ host = {"text": tsq.synth.text, "random": tsq.synth.random_bytes, "mix": tsq.syn
 host = host(n, 1) if host else np.zeros(n, dtype=np.uint8)
 src = torch.from_numpy(host).cuda()
 codec = tsq.DeviceCodec(0)
+codec.set_variant(int(os.environ.get("ENC_VARIANT", "0")), int(os.environ.get("DEC_VARIANT", "0")))
 blob = codec.compress(src, ext)
 back = codec.decompress(blob)
 assert torch.equal(back, src)
@@ -44,8 +45,8 @@ print("  BUILDER total=%.0f waited=%.0f busy=%.0f" % (e[18] / T, e[17] / T, (e[1
 print("  parser events per tile: stale-truncations=%.2f segments=%.2f hazard-lanes=%.2f (hard %.2f) replays=%.2f" % tuple(e[k] / T for k in (23, 24, 26, 27, 28)))
 print("  hazard lanes per tile by candidate: twin in tile=%.3f in t-1=%.3f in t-2=%.3f | twin far enough=%.3f | resolved as match=%.3f" % tuple(e[k] / T for k in (29, 30, 31, 20, 21)))
 print(f"  P6b detail (wave 0): init scan={d[9]} barrier waits={d[10]} read phases={d[11]} write phases={d[15]}")
-names = ["P0 stage", "P1 spec", "P2 dbl", "P3 chain", "P4 expand+scan", "P5 syms", "P6a scatter", "P6b jump", "P7 flush"]
+names = ["P0 stage", "P1 spec", "P2 dbl", "P3 chain(+flush)", "P4 expand+scan", "P5 pairs+copy", "P5 retry rounds", "P6 jump", "P7/bookkeeping"]
 dt = sum(d[:9])
-print(f"DEC block0: total ticks={dt} chunks={d[12]} jump rounds={d[13]} groups={d[14]}  thread0: vector history loads={d[9]} bytewise history loads={d[10]} pending bytes at P6b start={d[11]} image bytes={d[15]}")
+print(f"DEC block0: total ticks={dt} chunks={d[12]} retry rounds={d[13]} jump rounds={d[14]}  thread0: vector history loads={d[9]} bytewise history loads={d[10]} pending bytes at P6b start={d[11]} image bytes={d[15]}")
 for k, nm in enumerate(names):
     print(f"  {nm:16s} {d[k]:10d}  {100.0*d[k]/max(dt,1):5.1f}%  per chunk {d[k]/max(d[12],1):8.1f}")

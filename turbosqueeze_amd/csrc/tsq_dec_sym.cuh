@@ -1,0 +1,512 @@
+// tsq_dec_sym.cuh -- block decoder: speculative parse, one lane per symbol pair, byte lanes with asynchronous pointer jumping (kernel variant 0).
+//
+// The reference walks the stream with one dependent load per symbol (tsq_decode.cpp:62-88) and copies every symbol with a
+// 16-byte load/store.  Here each 6 KiB chunk of stream is staged in LDS and handled in data-parallel phases by one
+// workgroup of 16 wavefronts:
+//
+//   P0  stage the chunk (prefetched into registers while the previous chunk was being copied).
+//   P1  every byte offset is parsed AS IF a group (control byte + 4 pairs) started there: four chained lookups in a
+//       1024-entry table indexed by (two control bits, size byte) that gives a pair's stream length and output length.
+//   P2  pointer doubling: next^2, next^4, next^8, next^16 (all kept).
+//   P3  one lane follows next^16 from the known chunk start (one dependent LDS hop per 16 groups)  -- while the other
+//       fifteen wavefronts write the PREVIOUS chunk's bytes to HBM (P7).
+//   P4  one lane per group: its start from the hop it hangs on and the bits of its index (next^8, ^4, ^2, ^1: four
+//       dependent reads, all groups in parallel), then its four pairs' stream positions and output offsets; a block-wide
+//       scan gives the groups' output positions.
+//   P5  symbols -> bytes, with aligned, conflict-free LDS traffic only (an unaligned ds access costs 3.5x an aligned one on
+//       gfx950, tools/micro/lds_unaligned.hip):
+//       (a) one lane per PAIR decodes and validates its two symbols and drops one record word per symbol (kind, source delta)
+//           at the symbol's first byte index;
+//       (b) one lane per 12 output bytes (three aligned words of the ring): a "last record so far" scan hands every byte its
+//           symbol's record;
+//       (c) every byte fetches its value -- literal bytes from the stream buffer, history bytes from the 64 KiB of previous
+//           output kept in the ring -- or, when its source byte lies in this same chunk, a pointer to it;
+//       (d) asynchronous pointer jumping without barriers resolves those pointers in O(log chain depth) steps (every occurrence
+//           of a frequent word copies the one before it, so chains are as long as the chunk has occurrences);
+//       the chunk's bytes are composed IN the ring (77 KiB of LDS: 64 KiB of history + the chunk being built).
+//   P7  the chunk's bytes go from the ring to HBM with aligned 16-byte stores (overlapped with the next chunk's P3).
+//
+// Offsets and stream bounds are validated (the reference validates nothing); status codes as the oracle's decoder.
+#pragma once
+
+#include <type_traits>
+
+#include "tsq_common.cuh"
+#include "tsq_dec_common.cuh"
+
+namespace tsq {
+
+struct SymCfg {
+    static constexpr uint32_t T = 1024;
+    static constexpr uint32_t S = 6144;                    // stream bytes per chunk
+    static constexpr uint32_t SPAD = 160;                  // a group is at most 133 bytes
+    static constexpr uint32_t OUTC = 2 * S;                // output bytes per chunk at most
+    static constexpr uint32_t HOP = 16;
+    static constexpr uint32_t MAXG = 512;                  // >= S / 13 + 2 * HOP, a multiple of HOP
+    static constexpr uint32_t MAXSN = MAXG / HOP + 2;
+    static constexpr uint32_t PER = 8;                     // consecutive stream offsets per lane in P1 / P2
+    static constexpr uint32_t TP = S / PER;                // lanes that take part in P1 / P2
+    static constexpr uint32_t TERM = S + SPAD;             // "no group here": beyond every real offset
+    static constexpr uint32_t R = 65536 + OUTC + 64;       // ring: 64 KiB of history + the chunk being built (a multiple of 16)
+    static constexpr uint32_t RPAD = 64;
+    static constexpr uint32_t SWORDS = (S + SPAD + 16) / 16;   // 16-byte words of stream staged per chunk
+};
+struct SymLds {
+    static constexpr uint32_t sbuf = 0;                                             // u8[S + SPAD + 16]
+    static constexpr uint32_t j1 = sbuf + 16 * SymCfg::SWORDS;                      // u8[S]: next - offset
+    static constexpr uint32_t j2 = j1 + SymCfg::S;                                  // u16[S] each
+    static constexpr uint32_t j4 = j2 + 2 * SymCfg::S;
+    static constexpr uint32_t j8 = j4 + 2 * SymCfg::S;
+    static constexpr uint32_t j16 = j8 + 2 * SymCfg::S;
+    static constexpr uint32_t recw = j1;                                            // P5: u32[OUTC + 16] symbol records by first byte index, over j1 .. j16
+    static constexpr uint32_t ent = j1;                                             // P5: u16[OUTC + 16] byte entries (once the records are read)
+    static constexpr uint32_t plist = ent + 2 * (SymCfg::OUTC + 16);                // P5: u16[OUTC] per wavefront, the bytes that wait for a source
+    static constexpr uint32_t gstart = j16 + 2 * SymCfg::S;                         // u16[MAXG]
+    static constexpr uint32_t glen = gstart + 2 * SymCfg::MAXG;                     // u16[MAXG]
+    static constexpr uint32_t gout = glen + 2 * SymCfg::MAXG;                       // u32[MAXG]
+    static constexpr uint32_t pairs = gout + 4 * SymCfg::MAXG;                      // u32[4 * MAXG]: stream pos | out offset << 13 | 2 control bits << 30
+    static constexpr uint32_t sn = pairs + 16 * SymCfg::MAXG;                       // u16[MAXSN + pad]
+    static constexpr uint32_t wsum = (sn + 2 * ((SymCfg::MAXSN + 7) & ~7u) + 15) & ~15u;   // u32[16]
+    static constexpr uint32_t misc = wsum + 64;                                     // u32[16]
+    static constexpr uint32_t ring = (misc + 64 + 15) & ~15u;                       // u8[R + RPAD]
+    static constexpr uint32_t total = ring + SymCfg::R + SymCfg::RPAD;
+    static_assert(SymCfg::R % 16 == 0, "ring phase");
+    static_assert(recw % 16 == 0 && recw + 4 * (SymCfg::OUTC + 16) <= gstart && plist % 16 == 0 && plist + 2 * SymCfg::OUTC <= gstart,
+                  "records, byte entries and waiting lists fit the dead doubling tables");
+    static_assert(SymCfg::OUTC == 12 * SymCfg::T, "twelve bytes per lane");
+    static_assert(SymCfg::TP <= SymCfg::T && SymCfg::TP % 64 == 0 && SymCfg::SWORDS <= SymCfg::T, "lane counts");
+    static_assert(SymCfg::MAXG % SymCfg::HOP == 0 && SymCfg::MAXG >= SymCfg::S / 13 + 2 * SymCfg::HOP, "group table");
+};
+static_assert(SymLds::total <= 160 * 1024, "LDS budget");
+
+// length of a symbol from its nibble (tsq_decode.cpp:66-88,174-224)
+__device__ __forceinline__ uint32_t sym_out_len(uint32_t nib, uint32_t lit, uint32_t ext)
+{
+    return lit ? nib + 1u : ((ext && nib < 3u) ? (nib + 2u) << 4 : nib + 1u);
+}
+
+// stream bytes and output bytes of the pair whose size byte is `sb` and whose control bits are `cc` (bit 1: first symbol is a
+// literal, bit 0: second).  Arithmetic, not a table in LDS: the LDS pipe is the one unit all sixteen wavefronts share.
+__device__ __forceinline__ void pair_lens(uint32_t sb, uint32_t cc, uint32_t ext, uint32_t& slen, uint32_t& olen)
+{
+    const uint32_t hi = sb >> 4, lo = sb & 15u;
+    const uint32_t lit_hi = cc & 2u, lit_lo = cc & 1u;
+    const uint32_t o_hi = (!lit_hi && ext && hi < 3u) ? (hi + 2u) << 4 : hi + 1u;
+    const uint32_t o_lo = (!lit_lo && ext && lo < 3u) ? (lo + 2u) << 4 : lo + 1u;
+    slen = 1u + (lit_hi ? hi + 1u : 2u) + (lit_lo ? lo + 1u : 2u);
+    olen = o_hi + o_lo;
+}
+
+__global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict__ container, const FrameInfo* __restrict__ frames,
+                                                       uint8_t* __restrict__ outbuf, int32_t* __restrict__ status)
+{
+    using C = SymCfg;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t* const s_raw = lds + SymLds::sbuf;
+    uint8_t* const j1 = lds + SymLds::j1;
+    uint16_t* const j2 = reinterpret_cast<uint16_t*>(lds + SymLds::j2);
+    uint16_t* const j4 = reinterpret_cast<uint16_t*>(lds + SymLds::j4);
+    uint16_t* const j8 = reinterpret_cast<uint16_t*>(lds + SymLds::j8);
+    uint16_t* const j16 = reinterpret_cast<uint16_t*>(lds + SymLds::j16);
+    uint16_t* const gstart = reinterpret_cast<uint16_t*>(lds + SymLds::gstart);
+    uint16_t* const glen = reinterpret_cast<uint16_t*>(lds + SymLds::glen);
+    uint32_t* const gout = reinterpret_cast<uint32_t*>(lds + SymLds::gout);
+    uint32_t* const pairs = reinterpret_cast<uint32_t*>(lds + SymLds::pairs);
+    uint16_t* const sn = reinterpret_cast<uint16_t*>(lds + SymLds::sn);
+    uint32_t* const wsum = reinterpret_cast<uint32_t*>(lds + SymLds::wsum);
+    uint32_t* const misc = reinterpret_cast<uint32_t*>(lds + SymLds::misc);
+    uint8_t* const ring = lds + SymLds::ring;
+    uint32_t* const recw = reinterpret_cast<uint32_t*>(lds + SymLds::recw);
+    // misc[0] super nodes, [1] groups in chunk, [2] first group over the image budget, [3] group that completes the block,
+    // [4] error, [5] exit offset of the chain, [6] round stamp, [7] symbols on the waiting list
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    if (*status != 0) return;
+    const FrameInfo f = frames[blockIdx.x];
+    const uint8_t* const in = container + f.stream_at;
+    uint8_t* const out = outbuf + f.out_at;
+    const uint32_t in_len = f.stream_len, size = f.out_len, ext = f.ext;
+    // ring address of output position p: (p + oskew) mod R, so that 16-byte words of the ring are 16-byte words of HBM
+    const uint32_t oskew = (uint32_t)((uintptr_t)out & 15u);
+
+#ifdef TSQ_STATS
+    unsigned long long st_[16] = {0};
+#endif
+    TSQD_T0();
+    if (tid == 0) { misc[4] = 0; misc[6] = 0; misc[9] = 0; misc[10] = 0; }
+    uint32_t sp = 3, op = 0;
+    uint32_t ring_op = oskew;            // ring address of position op
+    uint32_t stamp = 0;
+    // what P7 still has to write out: the previous chunk's image
+    uint32_t prev_op = 0, prev_len = 0, prev_ring = 0;
+
+    auto flush_image = [&](uint32_t first_tid, uint32_t n_threads) {
+        // image bytes [prev_op, prev_op + prev_len) from the ring to HBM: head bytes up to the first aligned word, aligned
+        // 16-byte words, tail bytes.  Threads first_tid .. first_tid + n_threads - 1 take part.
+        if (prev_len == 0 || tid < first_tid) return;
+        const uint32_t t = tid - first_tid;
+        const uint32_t head = (16u - (prev_ring & 15u)) & 15u;
+        const uint32_t hb = head < prev_len ? head : prev_len;
+        if (t < hb) out[prev_op + t] = ring[prev_ring + t];                       // (the ring end is a multiple of 16: no wrap inside the head)
+        const uint32_t words = (prev_len - hb) >> 4;
+        uint32_t ra = prev_ring + hb; ra -= ra >= C::R ? C::R : 0u;
+        for (uint32_t w = t; w < words; w += n_threads) {
+            uint32_t a = ra + (w << 4); a -= a >= C::R ? C::R : 0u;
+            *reinterpret_cast<uint4*>(out + prev_op + hb + (w << 4)) = *reinterpret_cast<const uint4*>(ring + a);
+        }
+        const uint32_t tail_at = hb + (words << 4);
+        if (t < prev_len - tail_at) { uint32_t a = ra + (words << 4) + t; a -= a >= C::R ? C::R : 0u; out[prev_op + tail_at + t] = ring[a]; }
+    };
+
+    // P0 of the first chunk
+    uint4 pre = make_uint4(0, 0, 0, 0);
+    auto prefetch = [&](uint32_t at) {
+        // 16-byte word `tid` of the chunk that starts at stream offset `at`; zeros beyond the stream.  (Unaligned 16-byte global
+        // loads: the stream buffer in LDS then starts exactly at the chunk, and every LDS access to it is naturally aligned.)
+        const uint32_t avail = in_len - at;
+        const uint32_t lim = avail < C::S + C::SPAD ? avail : C::S + C::SPAD;
+        pre = make_uint4(0, 0, 0, 0);
+        if (tid < C::SWORDS) {
+            const uint32_t o = tid << 4;
+            if (o + 16u <= lim) __builtin_memcpy(&pre, in + at + o, 16);
+            else if (o < lim) {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (uint32_t k = 0; o + k < lim; ++k) w[k >> 2] |= (uint32_t)in[at + o + k] << (8u * (k & 3u));
+                pre = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+    };
+    prefetch(sp);
+    __syncthreads();
+
+    while (op < size) {
+        // ---------------- P0: the chunk (loaded a chunk ago) goes to LDS.  sbuf[k] = in[sp + k]; zeros beyond the stream.
+        const uint32_t avail = in_len - sp;
+        const uint32_t slim = avail < C::S ? avail : C::S;
+        uint8_t* const sbuf = s_raw;
+        if (tid < C::SWORDS) *reinterpret_cast<uint4*>(s_raw + (tid << 4)) = pre;
+        if (tid == 0) { misc[0] = 0; misc[1] = 0; misc[2] = 0xFFFFFFFFu; misc[3] = 0xFFFFFFFFu; misc[5] = 0; }
+        __syncthreads();
+        TSQD_ACC(0); TSQD_CNT(12, 1);
+
+        // ---------------- P1 + P2: speculative group parse at every offset, then next^2 .. next^16.  A lane owns PER = 8
+        // CONSECUTIVE offsets, so its own table entries are one 8- or 16-byte LDS access and stay in registers from pass to
+        // pass; only the reads at the offsets it points to are scattered.  An offset at or beyond slim is terminal (TERM).
+        {
+            uint32_t x[C::PER], y[C::PER];
+            const uint32_t o0 = tid * C::PER;
+            if (tid < C::TP) {
+                const uint2 cw = *reinterpret_cast<const uint2*>(sbuf + o0);
+#pragma unroll
+                for (uint32_t k = 0; k < C::PER; ++k) x[k] = o0 + k + 1u;
+#pragma unroll
+                for (uint32_t pr = 0; pr < 4; ++pr) {
+                    uint32_t sb[C::PER];
+#pragma unroll
+                    for (uint32_t k = 0; k < C::PER; ++k) sb[k] = sbuf[x[k]];                   // x < S + 133: inside the padded buffer
+#pragma unroll
+                    for (uint32_t k = 0; k < C::PER; ++k) {
+                        const uint32_t c = ((k < 4 ? cw.x : cw.y) >> (8u * (k & 3u))) & 0xFFu;
+                        uint32_t sl, ol;
+                        pair_lens(sb[k], (c >> (6u - 2u * pr)) & 3u, 0u, sl, ol);
+                        x[k] += sl;
+                    }
+                }
+                uint32_t d0 = 0, d1 = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) { d0 |= (x[k] - (o0 + k)) << (8u * k); d1 |= (x[k + 4] - (o0 + k + 4u)) << (8u * k); }
+                *reinterpret_cast<uint2*>(j1 + o0) = make_uint2(d0, d1);
+#pragma unroll
+                for (uint32_t k = 0; k < C::PER; ++k) x[k] = o0 + k < slim ? x[k] : C::TERM;
+            }
+            __syncthreads();
+            TSQD_ACC(1);
+            if (tid < C::TP) {
+#pragma unroll
+                for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t a = x[k] < slim ? x[k] : 0u; y[k] = a + j1[a]; }
+#pragma unroll
+                for (uint32_t k = 0; k < C::PER; ++k) x[k] = x[k] < slim ? y[k] : C::TERM;
+                *reinterpret_cast<uint4*>(j2 + o0) = make_uint4(x[0] | (x[1] << 16), x[2] | (x[3] << 16), x[4] | (x[5] << 16), x[6] | (x[7] << 16));
+            }
+            __syncthreads();
+            const uint16_t* src = j2;
+            uint16_t* const dsts[3] = {j4, j8, j16};
+#pragma unroll
+            for (uint32_t d = 0; d < 3; ++d) {
+                if (tid < C::TP) {
+#pragma unroll
+                    for (uint32_t k = 0; k < C::PER; ++k) y[k] = src[x[k] < slim ? x[k] : 0u];
+#pragma unroll
+                    for (uint32_t k = 0; k < C::PER; ++k) x[k] = x[k] < slim ? y[k] : C::TERM;
+                    *reinterpret_cast<uint4*>(dsts[d] + o0) = make_uint4(x[0] | (x[1] << 16), x[2] | (x[3] << 16), x[4] | (x[5] << 16), x[6] | (x[7] << 16));
+                }
+                __syncthreads();
+                src = dsts[d];
+            }
+        }
+        TSQD_ACC(2);
+
+        // ---------------- P3: one lane follows next^16 from the chunk start  ||  P7 of the previous chunk on the other waves
+        if (wid == 0) {
+            if (lane == 0) {
+                uint32_t x = 0, k = 0;
+                while (x < slim && k < C::MAXSN) { sn[k++] = (uint16_t)x; x = j16[x]; }
+                misc[0] = k;
+                if (k >= C::MAXSN && x < slim) misc[4] = kErrStream;
+            }
+        } else flush_image(64, C::T - 64);
+        __syncthreads();
+        const uint32_t nsn = misc[0];
+        TSQD_ACC(3);
+
+        // ---------------- P4: one lane per group.  Group 16 k + r starts where r's bits lead from super node k.
+        {
+            uint32_t x = C::TERM;
+            if (tid < nsn * C::HOP) {
+                x = sn[tid >> 4];
+                if (tid & 8u) x = x < slim ? j8[x] : C::TERM;
+                if (tid & 4u) x = x < slim ? j4[x] : C::TERM;
+                if (tid & 2u) x = x < slim ? j2[x] : C::TERM;
+                if (tid & 1u) x = x < slim ? (uint32_t)(x + j1[x]) : C::TERM;
+            }
+            uint32_t v = 0;
+            if (x < slim) {
+                gstart[tid] = (uint16_t)x;
+                const uint32_t c = sbuf[x];
+                uint32_t p = x + 1u, pw[4];
+#pragma unroll
+                for (uint32_t pr = 0; pr < 4; ++pr) {
+                    const uint32_t cc = (c >> (6u - 2u * pr)) & 3u;
+                    pw[pr] = p | (v << 13) | (cc << 30);                  // p < 2^13, v < 2^14 (the image budget)
+                    uint32_t sl, ol;
+                    pair_lens(sbuf[p], cc, ext, sl, ol);
+                    p += sl;
+                    v += ol;
+                }
+                *reinterpret_cast<uint4*>(pairs + tid * 4u) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+                glen[tid] = (uint16_t)v;
+                if (p >= slim) { misc[1] = tid + 1u; misc[5] = p; }       // the chunk's last group: the chain leaves the chunk here
+            }
+            uint32_t incl = v;
+#pragma unroll
+            for (uint32_t d = 1; d < 64; d <<= 1) { uint32_t up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+            if (lane == 63) wsum[wid] = incl;
+            __syncthreads();
+            uint32_t before = 0;
+            for (uint32_t w = 0; w < wid; ++w) before += wsum[w];
+            const uint32_t excl = before + incl - v;
+            if (x < slim) {
+                gout[tid] = op + excl;
+                if (excl + 512u + 16u > C::OUTC) atomicMin(&misc[2], tid);
+                if (op + excl + v >= size) atomicMin(&misc[3], tid);
+            }
+        }
+        __syncthreads();
+        uint32_t ng = misc[1];
+        uint32_t next_sp, next_op;
+        bool last_chunk = false;
+        {
+            const uint32_t cut = misc[2], fin = misc[3];
+            if (fin != 0xFFFFFFFFu && fin < cut) { ng = fin + 1; last_chunk = true; next_sp = sp; next_op = size; }
+            else if (cut != 0xFFFFFFFFu) { ng = cut; next_sp = sp + gstart[cut]; next_op = gout[cut]; }
+            else { next_sp = sp + misc[5]; next_op = ng ? gout[ng - 1] + glen[ng - 1] : op; }
+        }
+        if (misc[4] != 0 || ng == 0 || (!last_chunk && next_sp >= in_len)) {
+            if (tid == 0) atomicMax(status, kErrStream);
+            return;
+        }
+        const uint32_t image_len = next_op - op;
+        // the next chunk's stream is on its way while this one is copied
+        if (!last_chunk) prefetch(next_sp);
+        TSQD_ACC(4);
+
+        // ---------------- P5: symbols -> bytes.
+        // Image index i = (position - op) + lead, where lead = bytes of the ring word that holds position op which belong to the
+        // previous chunk: index 0 is a 4-byte aligned ring address, lane t owns indices [12 t, 12 t + 12) = three aligned ring words.
+        const uint32_t lead = ring_op & 3u;
+        const uint32_t a0 = ring_op - lead;                                            // ring address of index 0
+        // (a) one lane per PAIR: decode its two symbols, validate them, and drop one record word per symbol at the symbol's first
+        //     index: kind << 30 | 20-bit signed delta, where source index (or stream offset, for a literal) = own index + delta.
+        for (uint32_t w = tid; w < (C::OUTC + 16) / 4; w += C::T) *reinterpret_cast<uint4*>(recw + 4u * w) = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        uint32_t bad = 0;
+#pragma unroll 1
+        for (uint32_t gi = tid; gi < ng * 4u; gi += C::T) {
+            const uint32_t g = gi >> 2;
+            const uint32_t pw = pairs[gi];
+            uint32_t p = pw & 0x1FFFu, j = gout[g] + ((pw >> 13) & 0x3FFFu);
+            const uint32_t origin = j;
+            uint32_t sb = 0;
+            if (j < size) { if (p >= avail) bad = 1; sb = sbuf[p]; p++; }
+#pragma unroll
+            for (uint32_t sidx = 0; sidx < 2; ++sidx) {
+                if (j < size && !bad) {
+                    const uint32_t nib = sidx == 0 ? sb >> 4 : sb & 15u;
+                    const uint32_t lit = (pw >> (31u - sidx)) & 1u;
+                    const uint32_t room = size - j;
+                    const uint32_t ij = j - op + lead;
+                    if (lit) {
+                        const uint32_t len = nib + 1u, take = len < room ? len : room;
+                        if (p + take > avail) bad = 1;
+                        else recw[ij] = (1u << 30) | ((p - ij) & 0xFFFFFu);
+                        p += len; j += take;
+                    } else {
+                        if (p + 2u > avail) bad = 1;
+                        const uint32_t off = (uint32_t)sbuf[p] | ((uint32_t)sbuf[p + 1] << 8);
+                        p += 2;
+                        const uint32_t len = sym_out_len(nib, 0, ext);
+                        const uint32_t take = len < room ? len : room;
+                        if (off > origin || take > off) bad = 1;
+                        if (!bad) recw[ij] = (2u << 30) | ((0u - (j - (origin - off))) & 0xFFFFFu);   // source position - own position < 0
+                        j += take;
+                    }
+                }
+            }
+        }
+        if (bad) misc[4] = kErrStream;
+        __syncthreads();
+        if (misc[4] != 0) { if (tid == 0) atomicMax(status, (int32_t)misc[4]); return; }
+        TSQD_ACC(5);
+        // (b) one lane per 12 bytes: every byte takes the record of the symbol it lies in (the last record at or before it)
+        typedef __attribute__((address_space(3))) uint16_t lds_u16;
+        lds_u16* const le = (lds_u16*)(lds + SymLds::ent);                             // byte entries: 0x8000 | value when final, else source index
+        lds_u16* const wl = (lds_u16*)(lds + SymLds::plist) + 768u * wid;               // this wavefront's waiting list
+        const uint32_t own = 12u * tid;
+        uint32_t r[12];
+        {
+            const uint4 q0 = *reinterpret_cast<const uint4*>(recw + own), q1 = *reinterpret_cast<const uint4*>(recw + own + 4u),
+                        q2 = *reinterpret_cast<const uint4*>(recw + own + 8u);
+            r[0] = q0.x; r[1] = q0.y; r[2] = q0.z; r[3] = q0.w; r[4] = q1.x; r[5] = q1.y; r[6] = q1.z; r[7] = q1.w; r[8] = q2.x; r[9] = q2.y; r[10] = q2.z; r[11] = q2.w;
+#pragma unroll
+            for (uint32_t k = 1; k < 12; ++k) r[k] = r[k] ? r[k] : r[k - 1];
+            uint32_t v = r[11];                                                    // inclusive "last record so far" over the wavefront
+#pragma unroll
+            for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(v, d); if (lane >= d && v == 0u) v = up; }
+            uint32_t carry = __shfl_up(v, 1);
+            if (lane == 0) carry = 0;
+            if (lane == 63) wsum[wid] = v;
+            __syncthreads();                                                       // (also: every lane has taken its records out of `recw`)
+            {   // the last record of the wavefronts before this one: all sixteen words at once, the latest non-zero one below wid
+                const uint4 w0 = *reinterpret_cast<const uint4*>(wsum), w1 = *reinterpret_cast<const uint4*>(wsum + 4),
+                            w2 = *reinterpret_cast<const uint4*>(wsum + 8), w3 = *reinterpret_cast<const uint4*>(wsum + 12);
+                const uint32_t ws[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+                uint32_t prev = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < 16; ++w) prev = (w < wid && ws[w]) ? ws[w] : prev;
+                carry = carry ? carry : prev;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 12; ++k) r[k] = r[k] ? r[k] : carry;
+        }
+        // (c) where every byte comes from.  Final at once: literal bytes (stream buffer), bytes from before the chunk (ring), the
+        //     bytes in front of position op in the first word (kept).  Bytes whose source lies in this chunk point at it and
+        //     go onto the wavefront's waiting list.
+        const bool live = own < lead + image_len;
+        uint32_t pend = 0;
+        if (live) {
+            uint32_t addr[12], val[12];
+#pragma unroll
+            for (uint32_t k = 0; k < 12; ++k) {
+                const uint32_t i = own + k;
+                const uint32_t kind = r[k] >> 30;
+                const int32_t si = (int32_t)i + ((int32_t)(r[k] << 12) >> 12);
+                uint32_t x = a0 + C::R + (uint32_t)si;                               // history: ring address of index si < lead
+                x -= x >= C::R ? C::R : 0u; x -= x >= C::R ? C::R : 0u;
+                uint32_t self = a0 + i; self -= self >= C::R ? C::R : 0u;
+                addr[k] = kind == 1u ? (uint32_t)si : SymLds::ring + (kind == 2u ? x : self);   // (the stream buffer is at LDS offset 0)
+                val[k] = (uint32_t)si;
+                if (kind == 2u && si >= (int32_t)lead) pend |= 1u << k;
+            }
+            uint32_t by[12];
+#pragma unroll
+            for (uint32_t k = 0; k < 12; ++k) by[k] = lds[addr[k]];
+#pragma unroll
+            for (uint32_t k = 0; k < 12; ++k) val[k] = ((pend >> k) & 1u) ? val[k] : (0x8000u | by[k]);
+#pragma unroll
+            for (uint32_t w = 0; w < 3; ++w)
+                *reinterpret_cast<uint2*>(lds + SymLds::ent + 2u * own + 8u * w) = make_uint2(val[4 * w] | (val[4 * w + 1] << 16), val[4 * w + 2] | (val[4 * w + 3] << 16));
+        }
+        uint32_t n_wait = 0;                                                           // wavefront-uniform
+#pragma unroll
+        for (uint32_t k = 0; k < 12; ++k) {
+            const uint64_t m = __ballot((pend >> k) & 1u);
+            if ((pend >> k) & 1u) wl[n_wait + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint16_t)(own + k);
+            n_wait += (uint32_t)__builtin_popcountll(m);
+        }
+        __syncthreads();
+        TSQD_ACC(6);
+        // (d) asynchronous pointer jumping, no barriers, one lane per waiting byte: it reads its source's entry; a final entry
+        //     carries the value, any other entry is a pointer further back (entries only ever move towards the chain's root, so a
+        //     stale read is still a valid ancestor).  Chains of any depth (every occurrence of a frequent word copies the one
+        //     before it; runs of a short period) shrink geometrically.  Relaxed LDS atomics: plain ds_read / ds_write that the
+        //     compiler neither caches nor serialises.
+        {
+            uint32_t q[12], ptr[12];
+            uint32_t todo = 0;
+#pragma unroll
+            for (uint32_t ps = 0; ps < 12; ++ps) {
+                q[ps] = 0; ptr[ps] = 0;
+                if (ps * 64u < n_wait && ps * 64u + lane < n_wait) { q[ps] = wl[ps * 64u + lane]; todo |= 1u << ps; }
+            }
+#pragma unroll
+            for (uint32_t ps = 0; ps < 12; ++ps)
+                if (ps * 64u < n_wait) ptr[ps] = __hip_atomic_load(&le[q[ps]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef TSQ_STATS
+            uint32_t iters_ = 0;
+#endif
+            while (__ballot(todo != 0u) != 0ull) {
+                TSQD_CNT(13, 1);
+#ifdef TSQ_STATS
+                iters_++;
+#endif
+                uint32_t e[12];
+#pragma unroll
+                for (uint32_t ps = 0; ps < 12; ++ps)
+                    if (ps * 64u < n_wait) e[ps] = __hip_atomic_load(&le[((todo >> ps) & 1u) ? ptr[ps] : q[ps]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                for (uint32_t ps = 0; ps < 12; ++ps) {
+                    if (ps * 64u < n_wait && ((todo >> ps) & 1u)) {
+                        __hip_atomic_store(&le[q[ps]], (uint16_t)e[ps], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (e[ps] & 0x8000u) todo &= ~(1u << ps);
+                        else ptr[ps] = e[ps];
+                    }
+                }
+            }
+#ifdef TSQ_STATS
+            if (lane == 0) { atomicMax(&misc[9], iters_); atomicAdd(&misc[10], n_wait); }
+#endif
+        }
+        __syncthreads();
+        if (live) {                                                                    // every entry is final now: three aligned ring words per lane
+            const uint2 e0 = *reinterpret_cast<const uint2*>(lds + SymLds::ent + 2u * own), e1 = *reinterpret_cast<const uint2*>(lds + SymLds::ent + 2u * own + 8u),
+                        e2 = *reinterpret_cast<const uint2*>(lds + SymLds::ent + 2u * own + 16u);
+            const uint32_t ev[6] = {e0.x, e0.y, e1.x, e1.y, e2.x, e2.y};
+#pragma unroll
+            for (uint32_t w = 0; w < 3; ++w) {
+                uint32_t x = a0 + own + 4u * w; x -= x >= C::R ? C::R : 0u;
+                const uint32_t lo = ev[2 * w], hi = ev[2 * w + 1];
+                *reinterpret_cast<uint32_t*>(ring + x) = (lo & 0xFFu) | ((lo >> 8) & 0xFF00u) | ((hi & 0xFFu) << 16) | ((hi >> 16) << 24);
+            }
+        }
+        __syncthreads();
+        TSQD_ACC(7);
+#ifdef TSQ_STATS
+        if (tid == 0) { st_[14] += misc[9]; st_[11] += misc[10]; misc[9] = 0; misc[10] = 0; }
+#endif
+
+        // ---------------- the image is complete: it goes to HBM during the next chunk's P3 (or right now, after the last chunk)
+        prev_op = op; prev_len = image_len; prev_ring = ring_op;
+        ring_op += image_len; ring_op -= ring_op >= C::R ? C::R : 0u;
+        op = next_op;
+        sp = next_sp;
+        TSQD_ACC(8);
+        if (last_chunk) break;
+    }
+    __syncthreads();
+    flush_image(0, C::T);
+#ifdef TSQ_STATS
+    if (blockIdx.x == 0 && tid == 0) for (int q = 0; q < 16; ++q) g_dec_stats[q] = st_[q];
+#endif
+}
+
+}  // namespace tsq

@@ -13,6 +13,7 @@
 #include "tsq_internal.h"
 #include "tsq_serial.cuh"
 #include "tsq_dec_ring.cuh"
+#include "tsq_dec_sym.cuh"
 #include "tsq_enc_stage.cuh"
 #ifdef TSQ_AB_VARIANTS
 #include "ab/tsq_dec_fast.cuh"
@@ -100,8 +101,9 @@ inline int launch_decode_kernels(tsqa_ctx* c, const uint8_t* container, const Fr
 {
     static std::atomic<uint64_t> attr_devices{0};
     {
-        const void* const fns[2] = {reinterpret_cast<const void*>(dec_ring_kernel<true>), reinterpret_cast<const void*>(dec_ring_kernel<false>)};
-        const uint32_t bytes[2] = {RingLds::total, LeanLds::total};
+        const void* const fns[3] = {reinterpret_cast<const void*>(dec_ring_kernel<true>), reinterpret_cast<const void*>(dec_ring_kernel<false>),
+                                    reinterpret_cast<const void*>(dec_sym_kernel)};
+        const uint32_t bytes[3] = {RingLds::total, LeanLds::total, SymLds::total};
         if (int rc = raise_lds_limit(c, attr_devices, fns, bytes)) return rc;
     }
     const int v = c->dec_variant;
@@ -121,8 +123,10 @@ inline int launch_decode_kernels(tsqa_ctx* c, const uint8_t* container, const Fr
     // more blocks than CUs: the lean layout lets two blocks share a CU (variant 6 forces it, 7 never uses it)
     if (v == 6 || (v == 0 && n_blocks > (uint32_t)c->n_cus))
         hipLaunchKernelGGL(dec_ring_kernel<false>, dim3(n_blocks), dim3(LeanCfg::T), LeanLds::total, s, container, frames, out, status);
-    else
+    else if (v == 8)                   // the byte-granular ring decoder (the previous default), kept for A/B
         hipLaunchKernelGGL(dec_ring_kernel<true>, dim3(n_blocks), dim3(RingCfg::T), RingLds::total, s, container, frames, out, status);
+    else
+        hipLaunchKernelGGL(dec_sym_kernel, dim3(n_blocks), dim3(SymCfg::T), SymLds::total, s, container, frames, out, status);
     return 0;
 }
 
