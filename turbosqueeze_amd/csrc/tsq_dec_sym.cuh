@@ -44,8 +44,7 @@ struct SymCfg {
     static constexpr uint32_t HOP = 16;
     static constexpr uint32_t MAXG = 512;                  // >= S / 13 + 2 * HOP, a multiple of HOP
     static constexpr uint32_t MAXSN = MAXG / HOP + 2;
-    static constexpr uint32_t PER = 8;                     // consecutive stream offsets per lane in P1 / P2
-    static constexpr uint32_t TP = S / PER;                // lanes that take part in P1 / P2
+    static constexpr uint32_t PER = S / T;                 // stream offsets per lane in P1 / P2
     static constexpr uint32_t TERM = S + SPAD;             // "no group here": beyond every real offset
     static constexpr uint32_t R = 65536 + OUTC + 64;       // ring: 64 KiB of history + the chunk being built (a multiple of 16)
     static constexpr uint32_t RPAD = 64;
@@ -74,7 +73,7 @@ struct SymLds {
     static_assert(recw % 16 == 0 && recw + 4 * (SymCfg::OUTC + 16) <= gstart && plist % 16 == 0 && plist + 2 * SymCfg::OUTC <= gstart,
                   "records, byte entries and waiting lists fit the dead doubling tables");
     static_assert(SymCfg::OUTC == 12 * SymCfg::T, "twelve bytes per lane");
-    static_assert(SymCfg::TP <= SymCfg::T && SymCfg::TP % 64 == 0 && SymCfg::SWORDS <= SymCfg::T, "lane counts");
+    static_assert(SymCfg::S % SymCfg::T == 0 && SymCfg::SWORDS <= SymCfg::T, "lane counts");
     static_assert(SymCfg::MAXG % SymCfg::HOP == 0 && SymCfg::MAXG >= SymCfg::S / 13 + 2 * SymCfg::HOP, "group table");
 };
 static_assert(SymLds::total <= 160 * 1024, "LDS budget");
@@ -189,57 +188,42 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
         __syncthreads();
         TSQD_ACC(0); TSQD_CNT(12, 1);
 
-        // ---------------- P1 + P2: speculative group parse at every offset, then next^2 .. next^16.  A lane owns PER = 8
-        // CONSECUTIVE offsets, so its own table entries are one 8- or 16-byte LDS access and stay in registers from pass to
-        // pass; only the reads at the offsets it points to are scattered.  An offset at or beyond slim is terminal (TERM).
+        // ---------------- P1 + P2: speculative group parse at every offset, then next^2 .. next^16.  Lane t owns offsets t, t + T, ...:
+        // the lanes of a wavefront touch consecutive bytes, so neither their own entries nor the entries they point to (about one
+        // group further on, again consecutive) collide in the LDS banks.  A lane keeps its own entries in registers from pass to
+        // pass.  An offset at or beyond slim is terminal (TERM).
         {
-            uint32_t x[C::PER], y[C::PER];
-            const uint32_t o0 = tid * C::PER;
-            if (tid < C::TP) {
-                const uint2 cw = *reinterpret_cast<const uint2*>(sbuf + o0);
+            uint32_t x[C::PER], y[C::PER], c[C::PER];
 #pragma unroll
-                for (uint32_t k = 0; k < C::PER; ++k) x[k] = o0 + k + 1u;
+            for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t o = tid + k * C::T; c[k] = sbuf[o]; x[k] = o + 1u; }
 #pragma unroll
-                for (uint32_t pr = 0; pr < 4; ++pr) {
-                    uint32_t sb[C::PER];
+            for (uint32_t pr = 0; pr < 4; ++pr) {
 #pragma unroll
-                    for (uint32_t k = 0; k < C::PER; ++k) sb[k] = sbuf[x[k]];                   // x < S + 133: inside the padded buffer
+                for (uint32_t k = 0; k < C::PER; ++k) y[k] = sbuf[x[k]];                        // x < S + 133: inside the padded buffer
 #pragma unroll
-                    for (uint32_t k = 0; k < C::PER; ++k) {
-                        const uint32_t c = ((k < 4 ? cw.x : cw.y) >> (8u * (k & 3u))) & 0xFFu;
-                        uint32_t sl, ol;
-                        pair_lens(sb[k], (c >> (6u - 2u * pr)) & 3u, 0u, sl, ol);
-                        x[k] += sl;
-                    }
+                for (uint32_t k = 0; k < C::PER; ++k) {
+                    uint32_t sl, ol;
+                    pair_lens(y[k], (c[k] >> (6u - 2u * pr)) & 3u, 0u, sl, ol);
+                    x[k] += sl;
                 }
-                uint32_t d0 = 0, d1 = 0;
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) { d0 |= (x[k] - (o0 + k)) << (8u * k); d1 |= (x[k + 4] - (o0 + k + 4u)) << (8u * k); }
-                *reinterpret_cast<uint2*>(j1 + o0) = make_uint2(d0, d1);
-#pragma unroll
-                for (uint32_t k = 0; k < C::PER; ++k) x[k] = o0 + k < slim ? x[k] : C::TERM;
             }
+#pragma unroll
+            for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t o = tid + k * C::T; j1[o] = (uint8_t)(x[k] - o); x[k] = o < slim ? x[k] : C::TERM; }
             __syncthreads();
             TSQD_ACC(1);
-            if (tid < C::TP) {
 #pragma unroll
-                for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t a = x[k] < slim ? x[k] : 0u; y[k] = a + j1[a]; }
+            for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t a = x[k] < slim ? x[k] : 0u; y[k] = a + j1[a]; }
 #pragma unroll
-                for (uint32_t k = 0; k < C::PER; ++k) x[k] = x[k] < slim ? y[k] : C::TERM;
-                *reinterpret_cast<uint4*>(j2 + o0) = make_uint4(x[0] | (x[1] << 16), x[2] | (x[3] << 16), x[4] | (x[5] << 16), x[6] | (x[7] << 16));
-            }
+            for (uint32_t k = 0; k < C::PER; ++k) { x[k] = x[k] < slim ? y[k] : C::TERM; j2[tid + k * C::T] = (uint16_t)x[k]; }
             __syncthreads();
             const uint16_t* src = j2;
             uint16_t* const dsts[3] = {j4, j8, j16};
 #pragma unroll
             for (uint32_t d = 0; d < 3; ++d) {
-                if (tid < C::TP) {
 #pragma unroll
-                    for (uint32_t k = 0; k < C::PER; ++k) y[k] = src[x[k] < slim ? x[k] : 0u];
+                for (uint32_t k = 0; k < C::PER; ++k) y[k] = src[x[k] < slim ? x[k] : 0u];
 #pragma unroll
-                    for (uint32_t k = 0; k < C::PER; ++k) x[k] = x[k] < slim ? y[k] : C::TERM;
-                    *reinterpret_cast<uint4*>(dsts[d] + o0) = make_uint4(x[0] | (x[1] << 16), x[2] | (x[3] << 16), x[4] | (x[5] << 16), x[6] | (x[7] << 16));
-                }
+                for (uint32_t k = 0; k < C::PER; ++k) { x[k] = x[k] < slim ? y[k] : C::TERM; dsts[d][tid + k * C::T] = (uint16_t)x[k]; }
                 __syncthreads();
                 src = dsts[d];
             }
@@ -325,13 +309,20 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
         // previous chunk: index 0 is a 4-byte aligned ring address, lane t owns indices [12 t, 12 t + 12) = three aligned ring words.
         const uint32_t lead = ring_op & 3u;
         const uint32_t a0 = ring_op - lead;                                            // ring address of index 0
-        // (a) one lane per PAIR: decode its two symbols, validate them, and drop one record word per symbol at the symbol's first
-        //     index: kind << 30 | 20-bit signed delta, where source index (or stream offset, for a literal) = own index + delta.
+        // (a) one lane per PAIR: decode its two symbols, validate them, and drop a record word at the first byte index of every run
+        //     of bytes that come from one place: 0x40000000 | pointer flag << 31 | 24-bit signed D.
+        //       flag 0: the byte at index i is found at LDS address i + D (stream buffer for literals, ring for history);
+        //       flag 1: the byte at index i is a copy of the byte at index i + D of this same chunk (D < 0).
+        //     A literal is one run; a match is up to three (history before the ring's end, history after it, bytes of this chunk).
         for (uint32_t w = tid; w < (C::OUTC + 16) / 4; w += C::T) *reinterpret_cast<uint4*>(recw + 4u * w) = make_uint4(0, 0, 0, 0);
         __syncthreads();
+        if (tid == 0 && lead) recw[0] = 0x40000000u | (SymLds::ring + a0);          // the bytes in front of position op in the first word: kept
         uint32_t bad = 0;
-#pragma unroll 1
-        for (uint32_t gi = tid; gi < ng * 4u; gi += C::T) {
+        static_assert(4 * C::MAXG <= 2 * C::T, "at most two pairs per lane");
+#pragma unroll
+        for (uint32_t rep = 0; rep < 2; ++rep) {
+            const uint32_t gi = tid + rep * C::T;
+            if (gi >= ng * 4u) break;
             const uint32_t g = gi >> 2;
             const uint32_t pw = pairs[gi];
             uint32_t p = pw & 0x1FFFu, j = gout[g] + ((pw >> 13) & 0x3FFFu);
@@ -348,7 +339,7 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
                     if (lit) {
                         const uint32_t len = nib + 1u, take = len < room ? len : room;
                         if (p + take > avail) bad = 1;
-                        else recw[ij] = (1u << 30) | ((p - ij) & 0xFFFFFu);
+                        else recw[ij] = 0x40000000u | ((p - ij) & 0xFFFFFFu);
                         p += len; j += take;
                     } else {
                         if (p + 2u > avail) bad = 1;
@@ -357,7 +348,17 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
                         const uint32_t len = sym_out_len(nib, 0, ext);
                         const uint32_t take = len < room ? len : room;
                         if (off > origin || take > off) bad = 1;
-                        if (!bad) recw[ij] = (2u << 30) | ((0u - (j - (origin - off))) & 0xFFFFFu);   // source position - own position < 0
+                        if (!bad) {
+                            const uint32_t a = origin - off;                          // source position
+                            const uint32_t n_hist = a >= op ? 0u : (op - a < take ? op - a : take);
+                            if (n_hist) {
+                                uint32_t x0 = a0 + C::R - ((op - a) - lead);            // ring address of the first source byte (index a - op + lead < lead)
+                                x0 -= x0 >= C::R ? C::R : 0u;
+                                recw[ij] = 0x40000000u | ((SymLds::ring + x0 - ij) & 0xFFFFFFu);
+                                if (x0 + n_hist > C::R) { const uint32_t n1 = C::R - x0; recw[ij + n1] = 0x40000000u | ((SymLds::ring - (ij + n1)) & 0xFFFFFFu); }
+                            }
+                            if (n_hist < take) recw[ij + n_hist] = 0xC0000000u | ((a - j) & 0xFFFFFFu);   // source index - own index < 0
+                        }
                         j += take;
                     }
                 }
@@ -386,45 +387,34 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
             if (lane == 0) carry = 0;
             if (lane == 63) wsum[wid] = v;
             __syncthreads();                                                       // (also: every lane has taken its records out of `recw`)
-            {   // the last record of the wavefronts before this one: all sixteen words at once, the latest non-zero one below wid
-                const uint4 w0 = *reinterpret_cast<const uint4*>(wsum), w1 = *reinterpret_cast<const uint4*>(wsum + 4),
-                            w2 = *reinterpret_cast<const uint4*>(wsum + 8), w3 = *reinterpret_cast<const uint4*>(wsum + 12);
-                const uint32_t ws[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
-                uint32_t prev = 0;
-#pragma unroll
-                for (uint32_t w = 0; w < 16; ++w) prev = (w < wid && ws[w]) ? ws[w] : prev;
+            {   // the last record of the wavefronts before this one: lane w looks at wavefront w's, the highest one that has any wins
+                const uint32_t ws = lane < 16u ? wsum[lane] : 0u;
+                const uint64_t m = __ballot(ws != 0u && lane < wid);
+                const uint32_t prev = m ? (uint32_t)__builtin_amdgcn_readlane((int)ws, 63 - __builtin_clzll(m)) : 0u;
                 carry = carry ? carry : prev;
             }
 #pragma unroll
             for (uint32_t k = 0; k < 12; ++k) r[k] = r[k] ? r[k] : carry;
         }
-        // (c) where every byte comes from.  Final at once: literal bytes (stream buffer), bytes from before the chunk (ring), the
-        //     bytes in front of position op in the first word (kept).  Bytes whose source lies in this chunk point at it and
-        //     go onto the wavefront's waiting list.
+        // (c) every byte whose record names an LDS address is fetched at once (literal bytes, history bytes, the bytes kept in the
+        //     first word); every byte whose source lies in this chunk points at it and goes onto the wavefront's waiting list.
+        //     Entry per byte: 0x8000 | value when final, else the index of the source byte.
         const bool live = own < lead + image_len;
         uint32_t pend = 0;
         if (live) {
-            uint32_t addr[12], val[12];
+            uint32_t v[12], by[12];
 #pragma unroll
             for (uint32_t k = 0; k < 12; ++k) {
-                const uint32_t i = own + k;
-                const uint32_t kind = r[k] >> 30;
-                const int32_t si = (int32_t)i + ((int32_t)(r[k] << 12) >> 12);
-                uint32_t x = a0 + C::R + (uint32_t)si;                               // history: ring address of index si < lead
-                x -= x >= C::R ? C::R : 0u; x -= x >= C::R ? C::R : 0u;
-                uint32_t self = a0 + i; self -= self >= C::R ? C::R : 0u;
-                addr[k] = kind == 1u ? (uint32_t)si : SymLds::ring + (kind == 2u ? x : self);   // (the stream buffer is at LDS offset 0)
-                val[k] = (uint32_t)si;
-                if (kind == 2u && si >= (int32_t)lead) pend |= 1u << k;
+                v[k] = own + k + (uint32_t)((int32_t)(r[k] << 8) >> 8);               // LDS address of the byte, or index of its source
+                pend |= (r[k] >> 31) << k;
             }
-            uint32_t by[12];
 #pragma unroll
-            for (uint32_t k = 0; k < 12; ++k) by[k] = lds[addr[k]];
+            for (uint32_t k = 0; k < 12; ++k) by[k] = lds[(r[k] >> 31) ? 0u : v[k]];
 #pragma unroll
-            for (uint32_t k = 0; k < 12; ++k) val[k] = ((pend >> k) & 1u) ? val[k] : (0x8000u | by[k]);
+            for (uint32_t k = 0; k < 12; ++k) v[k] = (r[k] >> 31) ? v[k] : (0x8000u | by[k]);
 #pragma unroll
             for (uint32_t w = 0; w < 3; ++w)
-                *reinterpret_cast<uint2*>(lds + SymLds::ent + 2u * own + 8u * w) = make_uint2(val[4 * w] | (val[4 * w + 1] << 16), val[4 * w + 2] | (val[4 * w + 3] << 16));
+                *reinterpret_cast<uint2*>(lds + SymLds::ent + 2u * own + 8u * w) = make_uint2(v[4 * w] | (v[4 * w + 1] << 16), v[4 * w + 2] | (v[4 * w + 3] << 16));
         }
         uint32_t n_wait = 0;                                                           // wavefront-uniform
 #pragma unroll
@@ -441,37 +431,46 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
         //     before it; runs of a short period) shrink geometrically.  Relaxed LDS atomics: plain ds_read / ds_write that the
         //     compiler neither caches nor serialises.
         {
-            uint32_t q[12], ptr[12];
-            uint32_t todo = 0;
-#pragma unroll
-            for (uint32_t ps = 0; ps < 12; ++ps) {
-                q[ps] = 0; ptr[ps] = 0;
-                if (ps * 64u < n_wait && ps * 64u + lane < n_wait) { q[ps] = wl[ps * 64u + lane]; todo |= 1u << ps; }
-            }
-#pragma unroll
-            for (uint32_t ps = 0; ps < 12; ++ps)
-                if (ps * 64u < n_wait) ptr[ps] = __hip_atomic_load(&le[q[ps]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // The list is padded to whole passes of 64 with a spare entry of this wavefront (final from the start: a lane that sits
+            // on it re-writes what it read), and the loop is compiled for the number of passes so that it is straight-line code:
+            // all reads of an iteration in flight together, no branches.
+            const uint32_t spare = C::OUTC + wid;
+            if (lane == 0) le[spare] = 0x8000u;
+            const uint32_t passes = (n_wait + 63u) >> 6;
+            const uint32_t padded = passes <= 2u ? 2u : passes <= 4u ? 4u : passes <= 6u ? 6u : passes <= 8u ? 8u : 12u;
+            if (passes) for (uint32_t it = n_wait + lane; it < padded * 64u; it += 64u) wl[it] = (uint16_t)spare;
 #ifdef TSQ_STATS
             uint32_t iters_ = 0;
 #endif
-            while (__ballot(todo != 0u) != 0ull) {
-                TSQD_CNT(13, 1);
-#ifdef TSQ_STATS
-                iters_++;
-#endif
-                uint32_t e[12];
+            auto jump = [&](auto passes_c) {
+                constexpr uint32_t P = decltype(passes_c)::value;
+                uint32_t q[P], ptr[P];
 #pragma unroll
-                for (uint32_t ps = 0; ps < 12; ++ps)
-                    if (ps * 64u < n_wait) e[ps] = __hip_atomic_load(&le[((todo >> ps) & 1u) ? ptr[ps] : q[ps]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (uint32_t ps = 0; ps < P; ++ps) q[ps] = wl[ps * 64u + lane];
 #pragma unroll
-                for (uint32_t ps = 0; ps < 12; ++ps) {
-                    if (ps * 64u < n_wait && ((todo >> ps) & 1u)) {
+                for (uint32_t ps = 0; ps < P; ++ps) ptr[ps] = __hip_atomic_load(&le[q[ps]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (;;) {
+                    uint32_t e[P], open = 0;
+#pragma unroll
+                    for (uint32_t ps = 0; ps < P; ++ps) e[ps] = __hip_atomic_load(&le[(ptr[ps] & 0x8000u) ? q[ps] : ptr[ps]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                    for (uint32_t ps = 0; ps < P; ++ps) {
                         __hip_atomic_store(&le[q[ps]], (uint16_t)e[ps], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (e[ps] & 0x8000u) todo &= ~(1u << ps);
-                        else ptr[ps] = e[ps];
+                        ptr[ps] = e[ps];
+                        open |= (e[ps] & 0x8000u) ^ 0x8000u;
                     }
+#ifdef TSQ_STATS
+                    iters_++;
+#endif
+                    if (__ballot(open != 0u) == 0ull) break;
                 }
-            }
+            };
+            if (passes == 0u) {}
+            else if (passes <= 2u) jump(std::integral_constant<uint32_t, 2>{});
+            else if (passes <= 4u) jump(std::integral_constant<uint32_t, 4>{});
+            else if (passes <= 6u) jump(std::integral_constant<uint32_t, 6>{});
+            else if (passes <= 8u) jump(std::integral_constant<uint32_t, 8>{});
+            else jump(std::integral_constant<uint32_t, 12>{});
 #ifdef TSQ_STATS
             if (lane == 0) { atomicMax(&misc[9], iters_); atomicAdd(&misc[10], n_wait); }
 #endif
