@@ -167,10 +167,11 @@ int tsqa_profile_read_calls(tsqa_ctx *ctx, double *compress_ms, uint32_t *compre
  * kernel is priced against the HBM roofline. */
 int tsqa_measure_copy(tsqa_ctx *ctx, size_t bytes, int reps, double *best_gbps, double *median_gbps);
 
-/* Kernel variant selection: 0 = default (five-wave staged encoder, ring decoder; lean layouts by themselves when
- * there are more blocks than CUs), 1 = serial kernels (one lane walks the block; correctness baseline), 6 = force the
- * lean layouts (two blocks per CU), 7 = never lean.  Variants 2-5 (superseded kernel generations) exist only in the
- * A/B library built by `make ab`; the product library rejects them. */
+/* Kernel variant selection.  Encoder: 0 = default (five-wave staged encoder; its lean layout by itself when there are
+ * more blocks than CUs), 1 = serial kernel (one lane walks the block; correctness baseline), 6 = force the lean layout
+ * (two blocks per CU), 7 = never lean.  Decoder: 0 = default (byte-lane decoder), 1 = serial kernel.  The superseded
+ * kernel generations (encoder 2-5; decoder 2, 8, 9) exist only in the A/B library built by `make ab`; the product
+ * library rejects them. */
 void tsqa_set_kernel_variant(tsqa_ctx *ctx, int encode_variant, int decode_variant);
 
 /* =====================================================================================

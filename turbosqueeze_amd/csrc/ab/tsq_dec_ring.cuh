@@ -1,8 +1,9 @@
-// tsq_dec_ring.cuh -- wave-parallel block decoder with an LDS history ring (kernel variant 0).
+// tsq_dec_ring.cuh -- wave-parallel block decoder with an LDS history ring, byte-granular copies (A/B variants 8 and 9: superseded by
+// tsq_dec_sym.cuh, not in the product library).
 //
 // Phase structure: speculative group parse at every offset, pointer doubling, chain follow, group
 // scan, symbol records, pointer-jumping copy resolution (the first parallel decoder, now
-// ab/tsq_dec_fast.cuh, had the same phases), with the two things that one's profile asked for:
+// tsq_dec_fast.cuh, had the same phases), with the two things that one's profile asked for:
 //   * the last 64 KiB of output live in an LDS ring.  Match sources reach at most 65534 bytes
 //     before the start of their symbol pair (tsq_decode.cpp:73), i.e. never further back than the
 //     ring, so history bytes are read from LDS at byte granularity instead of gathering 16 bytes
@@ -16,8 +17,8 @@
 
 #include <type_traits>
 
-#include "tsq_common.cuh"
-#include "tsq_dec_common.cuh"
+#include "../tsq_common.cuh"
+#include "../tsq_dec_common.cuh"
 
 namespace tsq {
 

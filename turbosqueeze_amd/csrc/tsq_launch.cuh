@@ -1,8 +1,8 @@
 // tsq_launch.cuh -- kernel selection and launch for the device context.
 //
 // The product library carries three kernel families: the five-wave staged encoder (tsq_enc_stage.cuh, standard and lean
-// layouts, with and without extensions), the ring decoder (tsq_dec_ring.cuh, standard and lean) and the serial
-// correctness baselines (tsq_serial.cuh, variant 1).  The superseded generations (ab/: variants 2-5) are compiled only
+// layouts, with and without extensions), the byte-lane decoder (tsq_dec_sym.cuh) and the serial correctness baselines
+// (tsq_serial.cuh, variant 1).  The superseded generations (ab/: encoder variants 2-5, decoder variants 2, 8, 9) are compiled only
 // into the A/B library (`make ab`, -DTSQ_AB_VARIANTS), which tests/test_gpu_parity.py holds against the same oracle.
 #pragma once
 
@@ -12,11 +12,11 @@
 #include "tsq_emit.cuh"
 #include "tsq_internal.h"
 #include "tsq_serial.cuh"
-#include "tsq_dec_ring.cuh"
 #include "tsq_dec_sym.cuh"
 #include "tsq_enc_stage.cuh"
 #ifdef TSQ_AB_VARIANTS
 #include "ab/tsq_dec_fast.cuh"
+#include "ab/tsq_dec_ring.cuh"
 #include "ab/tsq_enc_fast.cuh"
 #include "ab/tsq_enc_orbit.cuh"
 #include "ab/tsq_enc_pipe.cuh"
@@ -101,32 +101,33 @@ inline int launch_decode_kernels(tsqa_ctx* c, const uint8_t* container, const Fr
 {
     static std::atomic<uint64_t> attr_devices{0};
     {
-        const void* const fns[3] = {reinterpret_cast<const void*>(dec_ring_kernel<true>), reinterpret_cast<const void*>(dec_ring_kernel<false>),
-                                    reinterpret_cast<const void*>(dec_sym_kernel)};
-        const uint32_t bytes[3] = {RingLds::total, LeanLds::total, SymLds::total};
+        const void* const fns[1] = {reinterpret_cast<const void*>(dec_sym_kernel)};
+        const uint32_t bytes[1] = {SymLds::total};
         if (int rc = raise_lds_limit(c, attr_devices, fns, bytes)) return rc;
     }
     const int v = c->dec_variant;
     if (v == 1) { hipLaunchKernelGGL(dec_serial_kernel, dim3(n_blocks), dim3(64), 0, s, container, frames, out, status); return 0; }
 #ifdef TSQ_AB_VARIANTS
-    if (v == 2) {                       // the first parallel decoder (history gathered from L2)
+    if (v == 2 || v == 8 || v == 9) {
         static std::atomic<uint64_t> ab_devices{0};
-        const void* const fns[1] = {reinterpret_cast<const void*>(dec_fast_kernel)};
-        const uint32_t bytes[1] = {DecLds::total};
+        const void* const fns[3] = {reinterpret_cast<const void*>(dec_fast_kernel), reinterpret_cast<const void*>(dec_ring_kernel<true>),
+                                    reinterpret_cast<const void*>(dec_ring_kernel<false>)};
+        const uint32_t bytes[3] = {DecLds::total, RingLds::total, LeanLds::total};
         if (int rc = raise_lds_limit(c, ab_devices, fns, bytes)) return rc;
-        hipLaunchKernelGGL(dec_fast_kernel, dim3(n_blocks), dim3(DecCfg::T), DecLds::total, s, container, frames, out, status);
+        if (v == 2)        // the first parallel decoder (history gathered from L2)
+            hipLaunchKernelGGL(dec_fast_kernel, dim3(n_blocks), dim3(DecCfg::T), DecLds::total, s, container, frames, out, status);
+        else if (v == 8)   // byte-granular copies, history ring in LDS (the previous default)
+            hipLaunchKernelGGL(dec_ring_kernel<true>, dim3(n_blocks), dim3(RingCfg::T), RingLds::total, s, container, frames, out, status);
+        else               // the same without the ring: two blocks per CU
+            hipLaunchKernelGGL(dec_ring_kernel<false>, dim3(n_blocks), dim3(LeanCfg::T), LeanLds::total, s, container, frames, out, status);
         return 0;
     }
 #else
-    if (v == 2) { c->set_error("kernel variant 2 lives in the A/B library only (make ab)"); return TSQA_ERR_ARG; }
+    if (v == 2 || v == 8 || v == 9) { c->set_error("kernel variant %d lives in the A/B library only (make ab)", v); return TSQA_ERR_ARG; }
 #endif
-    // more blocks than CUs: the lean layout lets two blocks share a CU (variant 6 forces it, 7 never uses it)
-    if (v == 6 || (v == 0 && n_blocks > (uint32_t)c->n_cus))
-        hipLaunchKernelGGL(dec_ring_kernel<false>, dim3(n_blocks), dim3(LeanCfg::T), LeanLds::total, s, container, frames, out, status);
-    else if (v == 8)                   // the byte-granular ring decoder (the previous default), kept for A/B
-        hipLaunchKernelGGL(dec_ring_kernel<true>, dim3(n_blocks), dim3(RingCfg::T), RingLds::total, s, container, frames, out, status);
-    else
-        hipLaunchKernelGGL(dec_sym_kernel, dim3(n_blocks), dim3(SymCfg::T), SymLds::total, s, container, frames, out, status);
+    // one workgroup per block at any block count: with more blocks than CUs the blocks simply queue (the decoder needs its 150 KB
+    // of LDS; the two-per-CU layout of the byte-granular decoder was 1.85x slower per byte, tools/config5_sweep.py)
+    hipLaunchKernelGGL(dec_sym_kernel, dim3(n_blocks), dim3(SymCfg::T), SymLds::total, s, container, frames, out, status);
     return 0;
 }
 
