@@ -212,9 +212,14 @@ def main():
     import turbosqueeze_amd as tsq
     from turbosqueeze_amd import sharding
 
-    world, rank, local_rank = init_distributed("nccl")
+    # (TSQ_BENCH_BACKEND=gloo TSQ_BENCH_SHARE_GPU=1: dry run of the N > 1 path with every rank on GPU 0 -- for a 1-GPU box)
+    backend = os.environ.get("TSQ_BENCH_BACKEND", "nccl")
+    world, rank, local_rank = init_distributed(backend)
+    if os.environ.get("TSQ_BENCH_SHARE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")       # where the small collectives' tensors live
 
     n = args.size
     nb = (n + tsq.BLOCK_SZ - 1) // tsq.BLOCK_SZ
@@ -240,7 +245,7 @@ def main():
             _, status = codec.last_size_status()
             assert status == 0, f"device status {status}"
         codec.profile(True)                               # HIP events around the kernels of the timed steps only
-        dt = timed_steps(step, steps, 0, world, torch.cuda.synchronize, dev)
+        dt = timed_steps(step, steps, 0, world, torch.cuda.synchronize, red_dev)
         kern = codec.profile_read()
         calls = codec.profile_read_calls()
         codec.profile(False)
@@ -305,7 +310,7 @@ def main():
         if rank != 0:
             hc = sharding.HostContainer(name, cap, create=False)
         hc.register()
-        sc = sharding.ShardedCodec(lay, sharding.DeviceBlocks(codec), hc, args.ext)
+        sc = sharding.ShardedCodec(lay, sharding.DeviceBlocks(codec, collective_device=red_dev), hc, args.ext)
         d_back = torch.empty(max(lay.shard_bytes, 1), dtype=torch.uint8, device=dev)
         size_seen = [0]
 
@@ -318,7 +323,7 @@ def main():
         for _ in range(args.warmup):
             step()
         codec.profile(True)
-        dt = timed_steps(step, args.steps, 0, world, torch.cuda.synchronize, dev)
+        dt = timed_steps(step, args.steps, 0, world, torch.cuda.synchronize, red_dev)
         enc_ms, enc_n, dec_ms, dec_n = codec.profile_read()
         codec.profile(False)
         assert torch.equal(d_back[:lay.shard_bytes], expect), "round trip mismatch on rank %d" % rank
@@ -328,7 +333,7 @@ def main():
             total, frame_at, sizes, ext_bits, out_len = sharding.walk_frames(hc.array, comp_bytes)
             assert total == n and len(sizes) == nb and int(frame_at[-1]) + 3 + int(sizes[-1]) == comp_bytes
         # the slowest rank's kernel times
-        kt = torch.tensor([enc_ms / max(enc_n, 1), dec_ms / max(dec_n, 1)], dtype=torch.float64, device=dev)
+        kt = torch.tensor([enc_ms / max(enc_n, 1), dec_ms / max(dec_n, 1)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(kt, op=dist.ReduceOp.MAX)
         hc.close()
         del d_shard, d_back, expect, sc

@@ -293,10 +293,31 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         MREG_END(13);
         MREG_BEGIN(14);
         if (EXT) {
+            // matches longer than 16 (tsq_encode.cpp:280-290): the next 16 bytes of both sides, up to 64.  They come from the window ring
+            // too when SCAN has already put the bytes up to p + 80 there (it usually runs two or three tiles ahead of MATCH); from global memory otherwise.
             uint32_t more = 16;
-            while (__ballot(k0 == more) != 0ull && more < 64u) {
-                if (k0 == more) k0 += prefix16(ld128z(src, (uint64_t)p + more, avail), ld128z(src, (uint64_t)cand0 + more, avail));
-                more += 16;
+            if (__ballot(k0 == more) != 0ull) {
+                const uint32_t scanned = uniform(__hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                const bool in_window = WINDOW && scanned >= t + 2u;        // everything below (t + 2) * 64 >= p + 48 + 16 is in the ring
+                auto win16 = [&](int32_t wi) -> uint4 {
+                    wi += wi < 0 ? (int32_t)StageCfg::WIN : 0;
+                    wi -= wi >= (int32_t)StageCfg::WIN ? (int32_t)StageCfg::WIN : 0;
+                    volatile lds_u32_t* wp = (volatile lds_u32_t*)(lds + StageCfg::off_win + ((uint32_t)wi & ~3u));
+                    const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2], d3 = wp[3], d4 = wp[4];
+                    const uint32_t sh = (uint32_t)wi & 3u;
+                    return make_uint4(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                                      __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh));
+                };
+                while (__ballot(k0 == more) != 0ull && more < 64u) {
+                    TSQ_CNT(20, in_window ? 1 : 0); TSQ_CNT(21, 1);
+                    if (k0 == more) {
+                        if (in_window && p - cand0 <= 65536u)
+                            k0 += prefix16(win16((int32_t)(wbase + lane + more)), win16((int32_t)(wbase + lane + more) - (int32_t)(p - cand0)));
+                        else
+                            k0 += prefix16(ld128z(src, (uint64_t)p + more, avail), ld128z(src, (uint64_t)cand0 + more, avail));
+                    }
+                    more += 16;
+                }
             }
         }
         const uint32_t dist = p - cand0;
@@ -329,7 +350,7 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         wbase = wbase + 64u == StageCfg::WIN ? 0u : wbase + 64u;
     }
 #ifdef TSQ_STATS
-    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[2] = st_[2]; g_enc_stats[3] = st_[3]; g_enc_stats[4] = TSQ_TOTAL(); g_enc_stats[13] = st_[13]; g_enc_stats[14] = st_[14]; }
+    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[2] = st_[2]; g_enc_stats[3] = st_[3]; g_enc_stats[4] = TSQ_TOTAL(); g_enc_stats[13] = st_[13]; g_enc_stats[14] = st_[14]; g_enc_stats[35] = st_[20]; g_enc_stats[36] = st_[21]; }
 #endif
 }
 
@@ -446,7 +467,7 @@ __device__ __forceinline__ uint32_t s_lsb64(uint64_t x)                   // x !
 // All parse state lives in uniform 32-bit integers (flags as 0/1, not bool: a bool that crosses a branch
 // becomes a 64-bit lane mask and costs VALU round trips), and the common paths are straight-line selects:
 // for a single wavefront a uniform branch costs more than the few instructions it skips.
-template <bool EXT>
+template <bool EXT, bool WINDOW>
 __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail, uint32_t n, lds_u8_t* lds, uint32_t lane)
 {
     volatile lds_u32_t* queue = (volatile lds_u32_t*)(lds + StageCfg::off_queue);
@@ -496,8 +517,9 @@ __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail,
         return make_uint4(q.x, q.y, q.z, q.w);
     };
 
+    uint32_t wbase = 0;                // (t * 64) % WIN
     TSQ_BEGIN();
-    for (uint32_t t = 0; done == 0u; ++t) {
+    for (uint32_t t = 0; done == 0u; ++t, wbase = wbase + 64u == StageCfg::WIN ? 0u : wbase + 64u) {
         const uint32_t base = t << 6;
         uint64_t vall = 0;
         if (v < base + 64u) {
@@ -719,8 +741,22 @@ __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail,
                     } else {
                         const uint32_t pend = s_lt(lit_from, i) & (am ^ 1u);   // a pending literal closes in front of the match (tsq_encode.cpp:103-118)
                         if (EXT && twin_cand) {
+                            // (the bytes behind the first 16 come from the input window ring when SCAN has put everything up to i + 64 there)
+                            const bool in_window = WINDOW && i - cand <= 65536u &&
+                                                   uniform(__hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= t + 2u;
+                            auto win16 = [&](int32_t wi) -> uint4 {
+                                wi += wi < 0 ? (int32_t)StageCfg::WIN : 0;
+                                wi -= wi >= (int32_t)StageCfg::WIN ? (int32_t)StageCfg::WIN : 0;
+                                volatile lds_u32_t* wp = (volatile lds_u32_t*)(lds + StageCfg::off_win + ((uint32_t)wi & ~3u));
+                                const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2], d3 = wp[3], d4 = wp[4];
+                                const uint32_t sh = (uint32_t)wi & 3u;
+                                return make_uint4(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                                                  __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh));
+                            };
                             while (k >= 16u && k < 64u && (k & 15u) == 0u) {
-                                const uint32_t add = uniform(prefix16(ld128z(src, (uint64_t)i + k, avail), ld128z(src, (uint64_t)cand + k, avail)));
+                                const int32_t wi = (int32_t)(wbase + L + k);
+                                const uint32_t add = in_window ? uniform(prefix16(win16(wi), win16(wi - (int32_t)(i - cand))))
+                                                               : uniform(prefix16(ld128z(src, (uint64_t)i + k, avail), ld128z(src, (uint64_t)cand + k, avail)));
                                 k += add;
                                 if (add < 16u) break;
                             }
@@ -817,7 +853,7 @@ __global__ __launch_bounds__(320) void enc_stage_kernel(const uint8_t* __restric
     lds_u8_t* lds3 = (lds_u8_t*)stage_lds;
     // Five waves on four SIMDs: waves 0 and 4 share one.  A wave64 VALU instruction occupies its SIMD for four cycles, so the
     // two that share should not both be VALU-heavy: the parser is almost pure SALU, the builder almost pure VALU.
-    if (role == 0) stage_parser<EXT>(src, avail, n, lds3, lane);
+    if (role == 0) stage_parser<EXT, WINDOW>(src, avail, n, lds3, lane);
     else if (role == 1) stage_scan<WINDOW>(src, avail, n, lds3, lane);
     else if (role == 2) stage_match<EXT, WINDOW>(src, avail, n, table, lds3, lane);
     else if (role == 3) stage_orbit<EXT>(n, lds3, lane);

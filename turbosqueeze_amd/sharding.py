@@ -235,9 +235,10 @@ class HostContainer:
 class DeviceBlocks:
     """The per-block device operations ShardedCodec needs, over tsqa_*_blocks_async (one GPU)."""
 
-    def __init__(self, codec):
+    def __init__(self, codec, collective_device=None):
         import torch
         self.codec, self.torch, self.device = codec, torch, codec.device
+        self.collective_device = collective_device or codec.device      # nccl: the GPU; gloo: the CPU
 
     def alloc(self, n_local: int):
         t = self.torch
@@ -248,7 +249,10 @@ class DeviceBlocks:
         self.codec.encode_blocks_async(d_in, n_local, stride, last_len, ext, self.slots, self.sizes)
 
     def sizes_tensor(self):
-        return self.sizes
+        # the sizes are needed on the host side of the gather now: wait for the encode kernel (it may run on the context's own
+        # stream, which torch's copies do not order themselves behind)
+        self.torch.cuda.synchronize(self.device)
+        return self.sizes if self.collective_device == self.device else self.sizes.to(self.collective_device)
 
     def frames_to_host(self, sizes, frame_at, ext, host):
         self.codec.frames_to_host_async(self.slots, sizes, frame_at, ext, host.ptr)
