@@ -384,7 +384,7 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
             const uint32_t p = (t << 6) + lane;
             const bool only2 = (tp2_lo | tp2_hi) != 0u && nearer == 0u && p < tail_from;
             if (__ballot(only2) != 0ull) {
-                if (!stage_wait(ctl, 5, t - 1u, 5)) break;                       // the parser has finished tile t-2
+                if (!stage_wait(ctl, 5, t - 1u, 5)) break;                   // the parser has finished tile t-2
                 const uint32_t slot = 16u + 2u * ((t - 2u) & 7u);
                 const uint32_t v2_lo = uniform(__hip_atomic_load(&ctl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 const uint32_t v2_hi = uniform(__hip_atomic_load(&ctl[slot + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -526,7 +526,16 @@ __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail,
             // ---- the tile's record
             REG_BEGIN(0); REG_END(0);
             REG_BEGIN(1);
-            (void)stage_wait(ctl, 4, t + 1u, 8);
+            // (the serial stage polls without sleeping: a wake-up from s_sleep costs it up to 64 cycles per hand-off)
+            if (!stage_ready(ctl, 4, t + 1u)) {
+#ifdef TSQ_STATS
+                const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
+#endif
+                while (!stage_ready(ctl, 4, t + 1u)) {}
+#ifdef TSQ_STATS
+                st_[8] += __builtin_amdgcn_s_memtime() - w0_;
+#endif
+            }
             TSQ_CNT(15, 1);
             volatile lds_u32_t* arr = recs + (t % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::ARR + lane;
             const uint32_t spanword = arr[kASpan * 64];
