@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 import turbosqueeze_amd as tsq
 from turbosqueeze_amd import api
 
-api.lib_path = lambda ab=False: os.path.join(ROOT, "turbosqueeze_amd", "libturbosqueeze_amd_stats.so")
+api.lib_path = lambda ab=False: os.path.join(ROOT, "turbosqueeze_amd", os.environ.get("STATS_LIB", "libturbosqueeze_amd_stats.so"))
 api._libs.clear()
 L = api.lib()
 L.tsqa_debug_stats.argtypes = [C.c_void_p, C.c_void_p]

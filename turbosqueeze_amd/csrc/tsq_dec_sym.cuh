@@ -67,7 +67,8 @@ struct SymLds {
     static constexpr uint32_t sn = pairs + 16 * SymCfg::MAXG;                       // u16[MAXSN + pad]
     static constexpr uint32_t wsum = (sn + 2 * ((SymCfg::MAXSN + 7) & ~7u) + 15) & ~15u;   // u32[16]
     static constexpr uint32_t misc = wsum + 64;                                     // u32[16]
-    static constexpr uint32_t ring = (misc + 64 + 15) & ~15u;                       // u8[R + RPAD]
+    static constexpr uint32_t lut = misc + 64;                                      // u16[1024]: (two control bits, size byte) -> stream bytes of the pair
+    static constexpr uint32_t ring = (lut + 2048 + 15) & ~15u;                      // u8[R + RPAD]
     static constexpr uint32_t total = ring + SymCfg::R + SymCfg::RPAD;
     static_assert(SymCfg::R % 16 == 0, "ring phase");
     static_assert(recw % 16 == 0 && recw + 4 * (SymCfg::OUTC + 16) <= gstart && plist % 16 == 0 && plist + 2 * SymCfg::OUTC <= gstart,
@@ -133,6 +134,8 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
 #endif
     TSQD_T0();
     if (tid == 0) { misc[4] = 0; misc[6] = 0; misc[9] = 0; misc[10] = 0; }
+    uint16_t* const lut = reinterpret_cast<uint16_t*>(lds + SymLds::lut);
+    { uint32_t sl, ol; pair_lens(tid & 255u, tid >> 8, 0u, sl, ol); lut[tid] = (uint16_t)sl; }
     uint32_t sp = 3, op = 0;
     uint32_t ring_op = oskew;            // ring address of position op
     uint32_t stamp = 0;
@@ -200,11 +203,21 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
             for (uint32_t pr = 0; pr < 4; ++pr) {
 #pragma unroll
                 for (uint32_t k = 0; k < C::PER; ++k) y[k] = sbuf[x[k]];                        // x < S + 133: inside the padded buffer
+#ifndef TSQ_P1_LUT_STEPS
+#define TSQ_P1_LUT_STEPS 0xF
+#endif
+                if ((TSQ_P1_LUT_STEPS >> pr) & 1) {                                              // pair length from the table in LDS ...
 #pragma unroll
-                for (uint32_t k = 0; k < C::PER; ++k) {
-                    uint32_t sl, ol;
-                    pair_lens(y[k], (c[k] >> (6u - 2u * pr)) & 3u, 0u, sl, ol);
-                    x[k] += sl;
+                    for (uint32_t k = 0; k < C::PER; ++k) y[k] = lut[(((c[k] >> (6u - 2u * pr)) & 3u) << 8) | y[k]];
+#pragma unroll
+                    for (uint32_t k = 0; k < C::PER; ++k) x[k] += y[k];
+                } else {                                                                         // ... or by arithmetic
+#pragma unroll
+                    for (uint32_t k = 0; k < C::PER; ++k) {
+                        uint32_t sl, ol;
+                        pair_lens(y[k], (c[k] >> (6u - 2u * pr)) & 3u, 0u, sl, ol);
+                        x[k] += sl;
+                    }
                 }
             }
 #pragma unroll
