@@ -85,6 +85,25 @@ __device__ __forceinline__ uint32_t sym_out_len(uint32_t nib, uint32_t lit, uint
     return lit ? nib + 1u : ((ext && nib < 3u) ? (nib + 2u) << 4 : nib + 1u);
 }
 
+// Inclusive scans over the 64 lanes of a wavefront with DPP row shifts and row broadcasts: six VALU instructions, no LDS round
+// trips (a __shfl_up is a ds_bpermute: an LDS-pipe operation with its latency, and the LDS pipe is what this kernel is short of).
+#define TSQ_DPP_SCAN_STEP(op, ctrl, rows)                                                                                        \
+    { const uint32_t t_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xF, false); v = op(v, t_); }
+__device__ __forceinline__ uint32_t dpp_add(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t dpp_max(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v)
+{
+    TSQ_DPP_SCAN_STEP(dpp_add, 0x111, 0xF) TSQ_DPP_SCAN_STEP(dpp_add, 0x112, 0xF) TSQ_DPP_SCAN_STEP(dpp_add, 0x114, 0xF) TSQ_DPP_SCAN_STEP(dpp_add, 0x118, 0xF)
+    TSQ_DPP_SCAN_STEP(dpp_add, 0x142, 0xA) TSQ_DPP_SCAN_STEP(dpp_add, 0x143, 0xC)      // row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v)                          // values >= 0; 0 is the identity
+{
+    TSQ_DPP_SCAN_STEP(dpp_max, 0x111, 0xF) TSQ_DPP_SCAN_STEP(dpp_max, 0x112, 0xF) TSQ_DPP_SCAN_STEP(dpp_max, 0x114, 0xF) TSQ_DPP_SCAN_STEP(dpp_max, 0x118, 0xF)
+    TSQ_DPP_SCAN_STEP(dpp_max, 0x142, 0xA) TSQ_DPP_SCAN_STEP(dpp_max, 0x143, 0xC)
+    return v;
+}
+
 // stream bytes and output bytes of the pair whose size byte is `sb` and whose control bits are `cc` (bit 1: first symbol is a
 // literal, bit 0: second).  Arithmetic, not a table in LDS: the LDS pipe is the one unit all sixteen wavefronts share.
 __device__ __forceinline__ void pair_lens(uint32_t sb, uint32_t cc, uint32_t ext, uint32_t& slen, uint32_t& olen)
@@ -284,9 +303,7 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
                 glen[tid] = (uint16_t)v;
                 if (p >= slim) { misc[1] = tid + 1u; misc[5] = p; }       // the chunk's last group: the chain leaves the chunk here
             }
-            uint32_t incl = v;
-#pragma unroll
-            for (uint32_t d = 1; d < 64; d <<= 1) { uint32_t up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+            const uint32_t incl = wave_scan_add(v);
             if (lane == 63) wsum[wid] = incl;
             __syncthreads();
             uint32_t before = 0;
@@ -393,12 +410,14 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
             r[0] = q0.x; r[1] = q0.y; r[2] = q0.z; r[3] = q0.w; r[4] = q1.x; r[5] = q1.y; r[6] = q1.z; r[7] = q1.w; r[8] = q2.x; r[9] = q2.y; r[10] = q2.z; r[11] = q2.w;
 #pragma unroll
             for (uint32_t k = 1; k < 12; ++k) r[k] = r[k] ? r[k] : r[k - 1];
-            uint32_t v = r[11];                                                    // inclusive "last record so far" over the wavefront
-#pragma unroll
-            for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(v, d); if (lane >= d && v == 0u) v = up; }
-            uint32_t carry = __shfl_up(v, 1);
-            if (lane == 0) carry = 0;
-            if (lane == 63) wsum[wid] = v;
+            // the last record of the lanes before this one: a max-scan over "1 + lane if it holds a record" names the lane, one
+            // ds_bpermute fetches the record from it
+            const uint32_t key = wave_scan_max(r[11] ? lane + 1u : 0u);
+            const uint32_t from = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x138, 0xF, 0xF, false);      // wave_shr:1 : the lanes strictly before
+            uint32_t carry = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((from ? from - 1u : 0u) << 2), (int)r[11]);
+            carry = from ? carry : 0u;
+            const uint32_t upto = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((key ? key - 1u : 0u) << 2), (int)r[11]);   // (every lane takes part: a
+            if (lane == 63) wsum[wid] = key ? upto : 0u;                                                                      //  bpermute reads active lanes only)
             __syncthreads();                                                       // (also: every lane has taken its records out of `recw`)
             {   // the last record of the wavefronts before this one: lane w looks at wavefront w's, the highest one that has any wins
                 const uint32_t ws = lane < 16u ? wsum[lane] : 0u;
@@ -429,12 +448,17 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
             for (uint32_t w = 0; w < 3; ++w)
                 *reinterpret_cast<uint2*>(lds + SymLds::ent + 2u * own + 8u * w) = make_uint2(v[4 * w] | (v[4 * w + 1] << 16), v[4 * w + 2] | (v[4 * w + 3] << 16));
         }
-        uint32_t n_wait = 0;                                                           // wavefront-uniform
+        uint32_t n_wait;                                                               // wavefront-uniform
+        {
+            const uint32_t cnt = (uint32_t)__builtin_popcount(pend);
+            const uint32_t incl = wave_scan_add(cnt);
+            n_wait = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            uint32_t at = incl - cnt;
 #pragma unroll
-        for (uint32_t k = 0; k < 12; ++k) {
-            const uint64_t m = __ballot((pend >> k) & 1u);
-            if ((pend >> k) & 1u) wl[n_wait + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint16_t)(own + k);
-            n_wait += (uint32_t)__builtin_popcountll(m);
+            for (uint32_t k = 0; k < 12; ++k) {
+                if ((pend >> k) & 1u) wl[at] = (uint16_t)(own + k);
+                at += (pend >> k) & 1u;
+            }
         }
         __syncthreads();
         TSQD_ACC(6);
