@@ -182,20 +182,14 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
     // P0 of the first chunk
     uint4 pre = make_uint4(0, 0, 0, 0);
     auto prefetch = [&](uint32_t at) {
-        // 16-byte word `tid` of the chunk that starts at stream offset `at`; zeros beyond the stream.  (Unaligned 16-byte global
-        // loads: the stream buffer in LDS then starts exactly at the chunk, and every LDS access to it is naturally aligned.)
+        // 16-byte word `tid` of the chunk that starts at stream offset `at`.  (Unaligned 16-byte global loads: the stream buffer in
+        // LDS then starts exactly at the chunk, and every LDS access to it is naturally aligned.)  Only whole words are loaded here,
+        // with no control flow behind the load, so that nothing waits for it before P0 of the next chunk; the last, partial word
+        // of a stream is fetched byte by byte in that P0.
         const uint32_t avail = in_len - at;
         const uint32_t lim = avail < C::S + C::SPAD ? avail : C::S + C::SPAD;
         pre = make_uint4(0, 0, 0, 0);
-        if (tid < C::SWORDS) {
-            const uint32_t o = tid << 4;
-            if (o + 16u <= lim) __builtin_memcpy(&pre, in + at + o, 16);
-            else if (o < lim) {
-                uint32_t w[4] = {0, 0, 0, 0};
-                for (uint32_t k = 0; o + k < lim; ++k) w[k >> 2] |= (uint32_t)in[at + o + k] << (8u * (k & 3u));
-                pre = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-        }
+        if (tid < C::SWORDS && (tid << 4) + 16u <= lim) __builtin_memcpy(&pre, in + at + (tid << 4), 16);
     };
     prefetch(sp);
     __syncthreads();
@@ -205,7 +199,16 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
         const uint32_t avail = in_len - sp;
         const uint32_t slim = avail < C::S ? avail : C::S;
         uint8_t* const sbuf = s_raw;
-        if (tid < C::SWORDS) *reinterpret_cast<uint4*>(s_raw + (tid << 4)) = pre;
+        if (tid < C::SWORDS) {
+            uint4 w = pre;
+            const uint32_t lim = avail < C::S + C::SPAD ? avail : C::S + C::SPAD, o = tid << 4;
+            if (o < lim && o + 16u > lim) {                                       // the stream's last, partial word (once per block)
+                uint32_t b[4] = {0, 0, 0, 0};
+                for (uint32_t k = 0; o + k < lim; ++k) b[k >> 2] |= (uint32_t)in[sp + o + k] << (8u * (k & 3u));
+                w = make_uint4(b[0], b[1], b[2], b[3]);
+            }
+            *reinterpret_cast<uint4*>(s_raw + (tid << 4)) = w;
+        }
         if (tid == 0) { misc[0] = 0; misc[1] = 0; misc[2] = 0xFFFFFFFFu; misc[3] = 0xFFFFFFFFu; misc[5] = 0; }
         __syncthreads();
         TSQD_ACC(0); TSQD_CNT(12, 1);
