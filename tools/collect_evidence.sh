@@ -1,0 +1,18 @@
+#!/bin/bash
+# Everything the round's numbers come from, collected on the GPU box into gpurun_out/$TAG (copy what is to be judged into profiles/).
+# Usage (on the GPU box, from the repo root): bash tools/collect_evidence.sh r02
+set -u
+TAG=${1:-rXX}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+(lscpu | head -25; echo "cgroup cpu.max: $(cat /sys/fs/cgroup/cpu.max 2>/dev/null)"; nproc; free -g | head -2; rocm-smi --showproductname 2>/dev/null | head -12) > $OUT/gpu_box_host.txt 2>&1
+(timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5) > $OUT/pytest_gpu.log
+(timeout 600 python bench.py --steps 10 --warmup 3 2>&1 | tail -1) > $OUT/bench.json
+bash tools/profile_round.sh $TAG > $OUT/profile_round.log 2>&1
+python tools/phase_stats.py > $OUT/phase_stats.txt 2>&1
+for n in 1073741824 4294967296; do timeout 300 python tools/config5_sweep.py $n 1 2>/dev/null; done > $OUT/config5.jsonl
+timeout 300 python tools/config5_sweep.py 1342177280 0 0 text 2>/dev/null >> $OUT/config5.jsonl
+for args in "--synthetic 1000000000 --reps 5 --no-ext" "--synthetic 1000000000 --reps 5" "--synthetic 4000000000 --reps 3"; do timeout 300 tools/tsq_cli b $args 2>/dev/null | tail -1; done > $OUT/cli_host_buffers.json
+tools/micro/lds_unaligned > $OUT/lds_access_costs.txt 2>&1
+TSQ_BENCH_BACKEND=gloo TSQ_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_2ranks_1gpu.json
+ls -la $OUT
