@@ -47,7 +47,7 @@ struct SymCfg {
     static constexpr uint32_t PER = S / T;                 // stream offsets per lane in P1 / P2
     static constexpr uint32_t TERM = S + SPAD;             // "no group here": beyond every real offset
     static constexpr uint32_t R = 65536 + OUTC + 64;       // ring: 64 KiB of history + the chunk being built (a multiple of 16)
-    static constexpr uint32_t RPAD = 64;
+    static constexpr uint32_t RPAD = 64;                   // slack behind the ring (the bytes past an image's end inherit its last record)
     static constexpr uint32_t SWORDS = (S + SPAD + 16) / 16;   // 16-byte words of stream staged per chunk
 };
 struct SymLds {
@@ -105,7 +105,7 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t v)                   
 }
 
 // stream bytes and output bytes of the pair whose size byte is `sb` and whose control bits are `cc` (bit 1: first symbol is a
-// literal, bit 0: second).  Arithmetic, not a table in LDS: the LDS pipe is the one unit all sixteen wavefronts share.
+// literal, bit 0: second) (tsq_decode.cpp:66-88,174-224)
 __device__ __forceinline__ void pair_lens(uint32_t sb, uint32_t cc, uint32_t ext, uint32_t& slen, uint32_t& olen)
 {
     const uint32_t hi = sb >> 4, lo = sb & 15u;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
     uint8_t* const ring = lds + SymLds::ring;
     uint32_t* const recw = reinterpret_cast<uint32_t*>(lds + SymLds::recw);
     // misc[0] super nodes, [1] groups in chunk, [2] first group over the image budget, [3] group that completes the block,
-    // [4] error, [5] exit offset of the chain, [6] round stamp, [7] symbols on the waiting list
+    // [4] error, [5] exit offset of the chain, [9], [10] instrumented builds only
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     if (*status != 0) return;
@@ -152,12 +152,11 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
     unsigned long long st_[16] = {0};
 #endif
     TSQD_T0();
-    if (tid == 0) { misc[4] = 0; misc[6] = 0; misc[9] = 0; misc[10] = 0; }
+    if (tid == 0) { misc[4] = 0; misc[9] = 0; misc[10] = 0; }
     uint16_t* const lut = reinterpret_cast<uint16_t*>(lds + SymLds::lut);
     { uint32_t sl, ol; pair_lens(tid & 255u, tid >> 8, 0u, sl, ol); lut[tid] = (uint16_t)sl; }
     uint32_t sp = 3, op = 0;
     uint32_t ring_op = oskew;            // ring address of position op
-    uint32_t stamp = 0;
     // what P7 still has to write out: the previous chunk's image
     uint32_t prev_op = 0, prev_len = 0, prev_ring = 0;
 
@@ -225,22 +224,12 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
             for (uint32_t pr = 0; pr < 4; ++pr) {
 #pragma unroll
                 for (uint32_t k = 0; k < C::PER; ++k) y[k] = sbuf[x[k]];                        // x < S + 133: inside the padded buffer
-#ifndef TSQ_P1_LUT_STEPS
-#define TSQ_P1_LUT_STEPS 0xF
-#endif
-                if ((TSQ_P1_LUT_STEPS >> pr) & 1) {                                              // pair length from the table in LDS ...
+                // the pair's stream length from a 2 KB table in LDS indexed by (two control bits, size byte): one more LDS read per step, but
+                // eight VALU instructions fewer (4.6 K cycles per chunk against 5.4 K by arithmetic)
 #pragma unroll
-                    for (uint32_t k = 0; k < C::PER; ++k) y[k] = lut[(((c[k] >> (6u - 2u * pr)) & 3u) << 8) | y[k]];
+                for (uint32_t k = 0; k < C::PER; ++k) y[k] = lut[(((c[k] >> (6u - 2u * pr)) & 3u) << 8) | y[k]];
 #pragma unroll
-                    for (uint32_t k = 0; k < C::PER; ++k) x[k] += y[k];
-                } else {                                                                         // ... or by arithmetic
-#pragma unroll
-                    for (uint32_t k = 0; k < C::PER; ++k) {
-                        uint32_t sl, ol;
-                        pair_lens(y[k], (c[k] >> (6u - 2u * pr)) & 3u, 0u, sl, ol);
-                        x[k] += sl;
-                    }
-                }
+                for (uint32_t k = 0; k < C::PER; ++k) x[k] += y[k];
             }
 #pragma unroll
             for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t o = tid + k * C::T; j1[o] = (uint8_t)(x[k] - o); x[k] = o < slim ? x[k] : C::TERM; }
@@ -309,8 +298,9 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
             const uint32_t incl = wave_scan_add(v);
             if (lane == 63) wsum[wid] = incl;
             __syncthreads();
-            uint32_t before = 0;
-            for (uint32_t w = 0; w < wid; ++w) before += wsum[w];
+            // output bytes of the wavefronts before this one: lane w takes wavefront w's total, one more scan, one readlane
+            const uint32_t totals = wave_scan_add(lane < C::T / 64u ? wsum[lane] : 0u);
+            const uint32_t before = wid ? (uint32_t)__builtin_amdgcn_readlane((int)totals, (int)wid - 1) : 0u;
             const uint32_t excl = before + incl - v;
             if (x < slim) {
                 gout[tid] = op + excl;
