@@ -8,8 +8,7 @@
 //   P1  every byte offset is parsed AS IF a group (control byte + 4 pairs) started there: four chained lookups in a
 //       1024-entry table indexed by (two control bits, size byte) that gives a pair's stream length and output length.
 //   P2  pointer doubling: next^2, next^4, next^8, next^16 (all kept).
-//   P3  one lane follows next^16 from the known chunk start (one dependent LDS hop per 16 groups)  -- while the other
-//       fifteen wavefronts write the PREVIOUS chunk's bytes to HBM (P7).
+//   P3  one lane follows next^16 from the known chunk start (one dependent LDS hop per 16 groups), with the LDS to itself.
 //   P4  one lane per group: its start from the hop it hangs on and the bits of its index (next^8, ^4, ^2, ^1: four
 //       dependent reads, all groups in parallel), then its four pairs' stream positions and output offsets; a block-wide
 //       scan gives the groups' output positions.
@@ -24,7 +23,8 @@
 //       (d) asynchronous pointer jumping without barriers resolves those pointers in O(log chain depth) steps (every occurrence
 //           of a frequent word copies the one before it, so chains are as long as the chunk has occurrences);
 //       the chunk's bytes are composed IN the ring (77 KiB of LDS: 64 KiB of history + the chunk being built).
-//   P7  the chunk's bytes go from the ring to HBM with aligned 16-byte stores (overlapped with the next chunk's P3).
+//   P7  the chunk's bytes go from the ring to HBM with aligned 16-byte stores, by the half of the workgroup that idles in the next
+//       chunk's P4.
 //
 // Offsets and stream bounds are validated (the reference validates nothing); status codes as the oracle's decoder.
 #pragma once
@@ -75,7 +75,7 @@ struct SymLds {
                   "records, byte entries and waiting lists fit the dead doubling tables");
     static_assert(SymCfg::OUTC == 12 * SymCfg::T, "twelve bytes per lane");
     static_assert(SymCfg::S % SymCfg::T == 0 && SymCfg::SWORDS <= SymCfg::T, "lane counts");
-    static_assert(SymCfg::MAXG % SymCfg::HOP == 0 && SymCfg::MAXG >= SymCfg::S / 13 + 2 * SymCfg::HOP, "group table");
+    static_assert(SymCfg::MAXG <= SymCfg::T / 2 && SymCfg::MAXG % SymCfg::HOP == 0 && SymCfg::MAXG >= SymCfg::S / 13 + 2 * SymCfg::HOP, "group table");
 };
 static_assert(SymLds::total <= 160 * 1024, "LDS budget");
 
@@ -255,19 +255,19 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
         TSQD_ACC(2);
 
         // ---------------- P3: one lane follows next^16 from the chunk start  ||  P7 of the previous chunk on the other waves
-        if (wid == 0) {
-            if (lane == 0) {
-                uint32_t x = 0, k = 0;
-                while (x < slim && k < C::MAXSN) { sn[k++] = (uint16_t)x; x = j16[x]; }
-                misc[0] = k;
-                if (k >= C::MAXSN && x < slim) misc[4] = kErrStream;
-            }
-        } else flush_image(64, C::T - 64);
+        if (tid == 0) {
+            uint32_t x = 0, k = 0;
+            while (x < slim && k < C::MAXSN) { sn[k++] = (uint16_t)x; x = j16[x]; }
+            misc[0] = k;
+            if (k >= C::MAXSN && x < slim) misc[4] = kErrStream;
+        }
         __syncthreads();
         const uint32_t nsn = misc[0];
         TSQD_ACC(3);
 
         // ---------------- P4: one lane per group.  Group 16 k + r starts where r's bits lead from super node k.
+        // (The upper half of the workgroup has no group to look after: it writes the PREVIOUS chunk's bytes to HBM meanwhile -- P7.)
+        if (tid >= C::T / 2) flush_image(C::T / 2, C::T / 2);
         {
             uint32_t x = C::TERM;
             if (tid < nsn * C::HOP) {
