@@ -17,8 +17,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     import torch
     import turbosqueeze_amd as tsq
     from turbosqueeze_amd import api
-    api.lib_path = lambda: os.path.join(ROOT, "turbosqueeze_amd", f"libturbosqueeze_amd_stats_r{k}.so")
-    api._lib = None
+    api.lib_path = lambda ab=False, k=k: os.path.join(ROOT, "turbosqueeze_amd", f"libturbosqueeze_amd_stats_r{k}.so")
+    api._libs.clear()
     L = api.lib()
     L.tsqa_debug_stats.argtypes = [C.c_void_p, C.c_void_p]
     n = 64 * (1 << 22)

@@ -6,8 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import turbosqueeze_amd as tsq
 from turbosqueeze_amd import api
-api.lib_path = lambda: os.path.join(ROOT, "turbosqueeze_amd", "libturbosqueeze_amd_stats.so")
-api._lib = None
+api.lib_path = lambda ab=False: os.path.join(ROOT, "turbosqueeze_amd", "libturbosqueeze_amd_stats.so")
+api._libs.clear()
 L = api.lib()
 data = np.fromfile(sys.argv[1], dtype=np.uint8)
 lo, hi = int(sys.argv[2]), int(sys.argv[3])
