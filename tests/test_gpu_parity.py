@@ -223,6 +223,34 @@ def test_more_blocks_than_cus_lean_layouts_full_compare(codec, oracle, tsq, kind
     assert torch.equal(back, dev)
 
 
+@pytest.mark.parametrize("kind", ["zeros", "random", "mix"])
+def test_config5_full_size_10gib(codec, oracle, tsq, kind):
+    """BASELINE.json config 5 at its full size, with extensions: 10 GiB = 2 560 blocks on one GPU (ten rounds of blocks; the 8-GPU
+    form shards the same blocks b % 8).  The WHOLE container against the oracle, and the round trip."""
+    import torch
+    n = 10 << 30
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+    except OSError:
+        lim = "max"
+    if lim != "max" and int(lim) < 6 * n:
+        pytest.skip("host memory limit too small for a 10 GiB input")
+    if torch.cuda.get_device_properties(0).total_memory < 6 * n:
+        pytest.skip("device memory too small for a 10 GiB input")
+    host = {"zeros": lambda: np.zeros(n, dtype=np.uint8), "random": lambda: tsq.synth.random_bytes(n, 25),
+            "mix": lambda: tsq.synth.mix(n, 23)}[kind]()
+    dev = to_dev(host)
+    blob = codec.compress(dev, 1)
+    back = codec.decompress(blob)
+    assert torch.equal(back, dev)
+    del back, dev
+    raw = blob.cpu().numpy()
+    del blob
+    torch.cuda.empty_cache()
+    want = np.frombuffer(oracle.compress(host, 1, threads=os.cpu_count() or 8), dtype=np.uint8)
+    assert raw.size == want.size and np.array_equal(raw, want)
+
+
 def test_config1_single_256k_block(tsq, oracle):
     """BASELINE.json config 1: one 262 144-byte block of enwik-shaped text through tsqEncode / tsqDecode, --no-ext."""
     data = tsq.synth.text(262144, seed=1).tobytes()
