@@ -74,6 +74,19 @@ def test_multi_device_scheduler_path(tsq, oracle, monkeypatch):
             assert tsq.tsq_decompress_mt(blob) == data, (batch, ext)
 
 
+def test_config4_eight_way_block_sharding_on_one_gpu(tsq, oracle, monkeypatch):
+    """BASELINE.json config 4 as far as one GPU can show it: the enwik9-sized job (239 blocks) cut by the scheduler into eight slices
+    of consecutive blocks, one per listed device (the one GPU listed eight times), each with its look-ahead, gathered on the host in
+    block order -- through the reference's own entry points.  The container is the oracle's; the round trip is exact."""
+    n = 1_000_000_000
+    host = tsq.synth.text(n, seed=9)
+    data = host.tobytes()
+    monkeypatch.setenv("TSQ_AMD_DEVICES", "0,0,0,0,0,0,0,0")
+    blob = tsq.tsq_compress_mt(data, False)
+    assert blob == oracle.compress(host, 0, threads=os.cpu_count() or 8)
+    assert tsq.tsq_decompress_mt(blob) == data
+
+
 def test_progress_fires_once_per_block_in_order(tsq):
     """tsq_threads.cpp:248-254,654-655: progress_cb once per written block, fractions k / n_blocks in order."""
     L = tsq.lib()
