@@ -307,6 +307,9 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
                 if (excl + 512u + 16u > C::OUTC) atomicMin(&misc[2], tid);
                 if (op + excl + v >= size) atomicMin(&misc[3], tid);
             }
+            // the doubling tables are dead from here on (every lane is past its last look-up in them): the record words of P5, which lie
+            // over them, are cleared now, under the barrier that is needed anyway
+            for (uint32_t w = tid; w < (C::OUTC + 16) / 4; w += C::T) *reinterpret_cast<uint4*>(recw + 4u * w) = make_uint4(0, 0, 0, 0);
         }
         __syncthreads();
         uint32_t ng = misc[1];
@@ -337,8 +340,6 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
         //       flag 0: the byte at index i is found at LDS address i + D (stream buffer for literals, ring for history);
         //       flag 1: the byte at index i is a copy of the byte at index i + D of this same chunk (D < 0).
         //     A literal is one run; a match is up to three (history before the ring's end, history after it, bytes of this chunk).
-        for (uint32_t w = tid; w < (C::OUTC + 16) / 4; w += C::T) *reinterpret_cast<uint4*>(recw + 4u * w) = make_uint4(0, 0, 0, 0);
-        __syncthreads();
         if (tid == 0 && lead) recw[0] = 0x40000000u | (SymLds::ring + a0);          // the bytes in front of position op in the first word: kept
         uint32_t bad = 0;
         static_assert(4 * C::MAXG <= 2 * C::T, "at most two pairs per lane");
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
                 *reinterpret_cast<uint32_t*>(ring + x) = (lo & 0xFFu) | ((lo >> 8) & 0xFF00u) | ((hi & 0xFFu) << 16) | ((hi >> 16) << 24);
             }
         }
-        __syncthreads();
+        // (no barrier here: nothing reads the ring, and nothing overwrites the entries, before the next chunk's P0 barrier)
         TSQD_ACC(7);
 #ifdef TSQ_STATS
         if (tid == 0) { st_[14] += misc[9]; st_[11] += misc[10]; misc[9] = 0; misc[10] = 0; }
