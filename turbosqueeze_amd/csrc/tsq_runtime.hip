@@ -399,7 +399,22 @@ extern "C" int tsqa_measure_copy(tsqa_ctx* c, size_t bytes, int reps, double* be
     if (hipMalloc(&a, words * 16) != hipSuccess || hipMalloc(&b, words * 16) != hipSuccess ||
         hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess ||
         hipMemsetAsync(a, 0x5a, words * 16, c->stream) != hipSuccess) rc = TSQA_ERR_HIP;
-    const uint32_t grid = (uint32_t)c->n_cus * 8u;
+    // the grid that copies fastest is found first (8, 16, 32 or 64 workgroups of 256 per CU), then measured `reps` times
+    uint32_t grid = (uint32_t)c->n_cus * 8u;
+    {
+        float best_ms = 1e30f;
+        for (uint32_t per_cu = 8; per_cu <= 64 && rc == TSQA_OK; per_cu *= 2) {
+            const uint32_t g = (uint32_t)c->n_cus * per_cu;
+            float ms = 1e30f;
+            for (int k = 0; k < 2; ++k) {
+                (void)hipEventRecord(e0, c->stream);
+                hipLaunchKernelGGL(copy_probe_kernel, dim3(g), dim3(256), 0, c->stream, a, b, words);
+                (void)hipEventRecord(e1, c->stream);
+                if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = TSQA_ERR_HIP; break; }
+            }
+            if (ms < best_ms) { best_ms = ms; grid = g; }
+        }
+    }
     for (int r = -1; r < reps && rc == TSQA_OK; ++r) {          // r == -1 warms up
         (void)hipEventRecord(e0, c->stream);
         hipLaunchKernelGGL(copy_probe_kernel, dim3(grid), dim3(256), 0, c->stream, a, b, words);
