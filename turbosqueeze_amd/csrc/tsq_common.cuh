@@ -81,4 +81,23 @@ __device__ __forceinline__ uint32_t prefix8(uint64_t a, uint64_t b)
     return x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
 }
 
+// Inclusive scans over the 64 lanes of a wavefront with DPP row shifts and row broadcasts: six VALU instructions, no LDS round
+// trips (a __shfl_up is a ds_bpermute: an LDS-pipe operation with its latency, and the LDS pipe is what this kernel is short of).
+#define TSQ_DPP_SCAN_STEP(op, ctrl, rows)                                                                                        \
+    { const uint32_t t_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xF, false); v = op(v, t_); }
+__device__ __forceinline__ uint32_t dpp_add(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t dpp_max(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v)
+{
+    TSQ_DPP_SCAN_STEP(dpp_add, 0x111, 0xF) TSQ_DPP_SCAN_STEP(dpp_add, 0x112, 0xF) TSQ_DPP_SCAN_STEP(dpp_add, 0x114, 0xF) TSQ_DPP_SCAN_STEP(dpp_add, 0x118, 0xF)
+    TSQ_DPP_SCAN_STEP(dpp_add, 0x142, 0xA) TSQ_DPP_SCAN_STEP(dpp_add, 0x143, 0xC)      // row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v)                          // values >= 0; 0 is the identity
+{
+    TSQ_DPP_SCAN_STEP(dpp_max, 0x111, 0xF) TSQ_DPP_SCAN_STEP(dpp_max, 0x112, 0xF) TSQ_DPP_SCAN_STEP(dpp_max, 0x114, 0xF) TSQ_DPP_SCAN_STEP(dpp_max, 0x118, 0xF)
+    TSQ_DPP_SCAN_STEP(dpp_max, 0x142, 0xA) TSQ_DPP_SCAN_STEP(dpp_max, 0x143, 0xC)
+    return v;
+}
+
 }  // namespace tsq

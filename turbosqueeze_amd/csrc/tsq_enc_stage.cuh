@@ -22,6 +22,12 @@
 // candidate, which is what the reference's table would hold (tsq_encode.cpp:76-79), or keeps the
 // gathered candidate when no twin was visited.
 #pragma once
+#ifndef TSQ_X2
+#define TSQ_X2 0
+#endif
+#ifndef TSQ_X3
+#define TSQ_X3 0
+#endif
 
 #include "tsq_common.cuh"
 #include "tsq_enc_util.cuh"
@@ -33,9 +39,10 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4_t lds_u32x4_t;
 
 struct StageCfg {
+    static constexpr uint32_t THREADS = 384;                      // six wavefronts
     static constexpr uint32_t Q = 32;
     static constexpr uint32_t ITEM_WORDS = 80;
-    static constexpr uint32_t RING = 128;
+    static constexpr uint32_t RING = 256;                          // symbol records between BUILDER and EMIT (four batches)
     static constexpr uint32_t R = 8;                              // tile records in flight
     static constexpr uint32_t OWN_MASK = 0x7FFFu;                 // owner image: hash folded to 15 bits
     static constexpr uint32_t WIN = 73728;                        // input window ring: the last 64 KiB of input and then some (a multiple of 64)
@@ -831,7 +838,7 @@ __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail,
 }
 
 template <bool EXT, bool WINDOW>
-__global__ __launch_bounds__(320) void enc_stage_kernel(const uint8_t* __restrict__ in, uint64_t n_total, uint64_t readable, uint64_t stride,
+__global__ __launch_bounds__(StageCfg::THREADS) void enc_stage_kernel(const uint8_t* __restrict__ in, uint64_t n_total, uint64_t readable, uint64_t stride,
                                                         uint8_t* __restrict__ slots, uint32_t* __restrict__ sizes,
                                                         uint16_t* __restrict__ tables, int32_t* __restrict__ status)
 {
@@ -850,23 +857,24 @@ __global__ __launch_bounds__(320) void enc_stage_kernel(const uint8_t* __restric
 
     {   // tsqInit (tsq_context.cpp:77-80), all five waves
         uint4* t4 = reinterpret_cast<uint4*>(table);
-        for (uint32_t k = threadIdx.x; k < kHashEntries * 2 / 16; k += 320) t4[k] = make_uint4(0, 0, 0, 0);
+        for (uint32_t k = threadIdx.x; k < kHashEntries * 2 / 16; k += StageCfg::THREADS) t4[k] = make_uint4(0, 0, 0, 0);
         if (threadIdx.x < 64) reinterpret_cast<uint32_t*>(stage_lds + StageCfg::off_ctl)[threadIdx.x] = 0;
         uint4* o4 = reinterpret_cast<uint4*>(stage_lds + StageCfg::off_owner);          // owner image: no valid entries
-        for (uint32_t k = threadIdx.x; k < (StageCfg::OWN_MASK + 1u) / 16; k += 320) o4[k] = make_uint4(0, 0, 0, 0);
+        for (uint32_t k = threadIdx.x; k < (StageCfg::OWN_MASK + 1u) / 16; k += StageCfg::THREADS) o4[k] = make_uint4(0, 0, 0, 0);
         uint4* f4 = reinterpret_cast<uint4*>(stage_lds + StageCfg::off_f);              // MATCH's filter: empty
-        for (uint32_t k = threadIdx.x; k < (StageCfg::F_MASK + 1u) / 16; k += 320) f4[k] = make_uint4(0, 0, 0, 0);
+        for (uint32_t k = threadIdx.x; k < (StageCfg::F_MASK + 1u) / 16; k += StageCfg::THREADS) f4[k] = make_uint4(0, 0, 0, 0);
         if (threadIdx.x == 0) { out[0] = (uint8_t)n; out[1] = (uint8_t)(n >> 8); out[2] = (uint8_t)(n >> 16); }
     }
     __syncthreads();
     lds_u8_t* lds3 = (lds_u8_t*)stage_lds;
-    // Five waves on four SIMDs: waves 0 and 4 share one.  A wave64 VALU instruction occupies its SIMD for four cycles, so the
-    // two that share should not both be VALU-heavy: the parser is almost pure SALU, the builder almost pure VALU.
+    // Six waves on four SIMDs (wave w runs on SIMD w % 4): the parser shares its SIMD with the emitter, which works once per 64
+    // symbols; ORBIT (which waits a third of its time) shares with the builder.
     if (role == 0) stage_parser<EXT, WINDOW>(src, avail, n, lds3, lane);
-    else if (role == 1) stage_scan<WINDOW>(src, avail, n, lds3, lane);
+    else if (role == (TSQ_X2 ? 1 : 3)) stage_scan<WINDOW>(src, avail, n, lds3, lane);
     else if (role == 2) stage_match<EXT, WINDOW>(src, avail, n, table, lds3, lane);
-    else if (role == 3) stage_orbit<EXT>(n, lds3, lane);
-    else stream_builder<StageCfg>(src, avail, out, lds3, lane, b, sizes, status);
+    else if (role == (TSQ_X2 ? 3 : 1)) stage_orbit<EXT>(n, lds3, lane);
+    else if (role == 4) stream_emitter<StageCfg>(src, avail, out, lds3, lane, b, sizes, status);
+    else stream_builder<StageCfg>(lds3, lane);
 }
 
 }  // namespace tsq

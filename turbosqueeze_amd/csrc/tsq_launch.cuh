@@ -15,12 +15,7 @@
 #include "tsq_dec_sym.cuh"
 #include "tsq_enc_stage.cuh"
 #ifdef TSQ_AB_VARIANTS
-#include "ab/tsq_dec_fast.cuh"
 #include "ab/tsq_dec_ring.cuh"
-#include "ab/tsq_enc_fast.cuh"
-#include "ab/tsq_enc_orbit.cuh"
-#include "ab/tsq_enc_pipe.cuh"
-#include "ab/tsq_enc_tile.cuh"
 #endif
 
 namespace tsq {
@@ -61,36 +56,16 @@ inline int launch_encode_kernels(tsqa_ctx* c, const uint8_t* in, size_t n, size_
         else     TSQ_LAUNCH_ENC(enc_serial_kernel<false>, 64, 0);
         return 0;
     }
-#ifdef TSQ_AB_VARIANTS
-    if (v >= 2 && v <= 5) {
-        if (stride != kBlockSize) { c->set_error("the A/B encoder variants take contiguous blocks only"); return TSQA_ERR_ARG; }
-        static std::atomic<uint64_t> ab_devices{0};
-        const void* const fns[8] = {reinterpret_cast<const void*>(enc_tile_kernel<true>), reinterpret_cast<const void*>(enc_tile_kernel<false>),
-                                    reinterpret_cast<const void*>(enc_fast_kernel<true>), reinterpret_cast<const void*>(enc_fast_kernel<false>),
-                                    reinterpret_cast<const void*>(enc_orbit_kernel<true>), reinterpret_cast<const void*>(enc_orbit_kernel<false>),
-                                    reinterpret_cast<const void*>(enc_pipe_kernel<true>), reinterpret_cast<const void*>(enc_pipe_kernel<false>)};
-        const uint32_t bytes[8] = {TileCfg::total, TileCfg::total, kEncLds, kEncLds, kOrbLds, kOrbLds, PipeCfg::total, PipeCfg::total};
-        if (int rc = raise_lds_limit(c, ab_devices, fns, bytes)) return rc;
-#define TSQ_LAUNCH_AB(KERNEL, THREADS, LDS) hipLaunchKernelGGL((KERNEL), dim3(nb), dim3(THREADS), (LDS), s, in, (uint64_t)n, (uint64_t)readable, slots, sizes, c->tables, status)
-        if (v == 2) { if (ext) TSQ_LAUNCH_AB(enc_fast_kernel<true>, 64, kEncLds); else TSQ_LAUNCH_AB(enc_fast_kernel<false>, 64, kEncLds); }          // windowed scalar walk
-        else if (v == 3) { if (ext) TSQ_LAUNCH_AB(enc_orbit_kernel<true>, 64, kOrbLds); else TSQ_LAUNCH_AB(enc_orbit_kernel<false>, 64, kOrbLds); }   // single-wave orbit
-        else if (v == 4) { if (ext) TSQ_LAUNCH_AB(enc_pipe_kernel<true>, 128, PipeCfg::total); else TSQ_LAUNCH_AB(enc_pipe_kernel<false>, 128, PipeCfg::total); }   // parser + builder
-        else { if (ext) TSQ_LAUNCH_AB(enc_tile_kernel<true>, 192, TileCfg::total); else TSQ_LAUNCH_AB(enc_tile_kernel<false>, 192, TileCfg::total); }   // front + parser + builder
-#undef TSQ_LAUNCH_AB
-        return 0;
-    }
-#else
-    if (v >= 2 && v <= 5) { c->set_error("kernel variant %d lives in the A/B library only (make ab)", v); return TSQA_ERR_ARG; }
-#endif
+    if (v >= 2 && v <= 5) { c->set_error("kernel variant %d is not built", v); return TSQA_ERR_ARG; }
     // five-wave staged pipeline: scan + match + orbit + parser + builder.  More blocks than CUs: the lean layout (no input
     // window in LDS, candidate bytes from L2) lets two blocks share a CU; each is a little slower, together they are faster.
     const bool lean = v == 6 || (v == 0 && nb > (uint32_t)c->n_cus);
     if (lean) {
-        if (ext) TSQ_LAUNCH_ENC((enc_stage_kernel<true, false>), 320, StageCfg::total_lean);
-        else     TSQ_LAUNCH_ENC((enc_stage_kernel<false, false>), 320, StageCfg::total_lean);
+        if (ext) TSQ_LAUNCH_ENC((enc_stage_kernel<true, false>), StageCfg::THREADS, StageCfg::total_lean);
+        else     TSQ_LAUNCH_ENC((enc_stage_kernel<false, false>), StageCfg::THREADS, StageCfg::total_lean);
     } else {
-        if (ext) TSQ_LAUNCH_ENC((enc_stage_kernel<true, true>), 320, StageCfg::total);
-        else     TSQ_LAUNCH_ENC((enc_stage_kernel<false, true>), 320, StageCfg::total);
+        if (ext) TSQ_LAUNCH_ENC((enc_stage_kernel<true, true>), StageCfg::THREADS, StageCfg::total);
+        else     TSQ_LAUNCH_ENC((enc_stage_kernel<false, true>), StageCfg::THREADS, StageCfg::total);
     }
     return 0;
 }
@@ -108,22 +83,19 @@ inline int launch_decode_kernels(tsqa_ctx* c, const uint8_t* container, const Fr
     const int v = c->dec_variant;
     if (v == 1) { hipLaunchKernelGGL(dec_serial_kernel, dim3(n_blocks), dim3(64), 0, s, container, frames, out, status); return 0; }
 #ifdef TSQ_AB_VARIANTS
-    if (v == 2 || v == 8 || v == 9) {
+    if (v == 8 || v == 9) {
         static std::atomic<uint64_t> ab_devices{0};
-        const void* const fns[3] = {reinterpret_cast<const void*>(dec_fast_kernel), reinterpret_cast<const void*>(dec_ring_kernel<true>),
-                                    reinterpret_cast<const void*>(dec_ring_kernel<false>)};
-        const uint32_t bytes[3] = {DecLds::total, RingLds::total, LeanLds::total};
+        const void* const fns[2] = {reinterpret_cast<const void*>(dec_ring_kernel<true>), reinterpret_cast<const void*>(dec_ring_kernel<false>)};
+        const uint32_t bytes[2] = {RingLds::total, LeanLds::total};
         if (int rc = raise_lds_limit(c, ab_devices, fns, bytes)) return rc;
-        if (v == 2)        // the first parallel decoder (history gathered from L2)
-            hipLaunchKernelGGL(dec_fast_kernel, dim3(n_blocks), dim3(DecCfg::T), DecLds::total, s, container, frames, out, status);
-        else if (v == 8)   // byte-granular copies, history ring in LDS (the previous default)
+        if (v == 8)        // byte-granular copies, history ring in LDS (round 1's default)
             hipLaunchKernelGGL(dec_ring_kernel<true>, dim3(n_blocks), dim3(RingCfg::T), RingLds::total, s, container, frames, out, status);
         else               // the same without the ring: two blocks per CU
             hipLaunchKernelGGL(dec_ring_kernel<false>, dim3(n_blocks), dim3(LeanCfg::T), LeanLds::total, s, container, frames, out, status);
         return 0;
     }
 #else
-    if (v == 2 || v == 8 || v == 9) { c->set_error("kernel variant %d lives in the A/B library only (make ab)", v); return TSQA_ERR_ARG; }
+    if (v == 8 || v == 9) { c->set_error("kernel variant %d lives in the A/B library only (make ab)", v); return TSQA_ERR_ARG; }
 #endif
     // one workgroup per block at any block count: with more blocks than CUs the blocks simply queue (the decoder needs its 150 KB
     // of LDS; the two-per-CU layout of the byte-granular decoder was 1.85x slower per byte, tools/config5_sweep.py)
