@@ -40,11 +40,13 @@ print("          suspect lanes per tile=%.2f (from previous tiles %.2f), group r
 print("  MATCH   total=%.0f waited(scan)=%.0f waited(parser)=%.0f busy=%.0f" % (e[4] / T, e[2] / T, e[3] / T, (e[4] - e[2] - e[3]) / T))
 print("          length-extension rounds per tile=%.2f (from the window ring %.2f)" % (e[36] / T, e[35] / T))
 print("  ORBIT   total=%.0f waited=%.0f busy=%.0f" % (e[7] / T, e[6] / T, (e[7] - e[6]) / T))
-print("  PARSER  total=%.0f waited(orbit)=%.0f waited(queue)=%.0f busy=%.0f" % (e[10] / T, e[8] / T, e[9] / T, (e[10] - e[8] - e[9]) / T))
+print("  WALK    total=%.0f waited(orbit)=%.0f waited(events)=%.0f waited(answers)=%.0f busy=%.0f  queries per tile=%.3f" % (e[10] / T, e[8] / T, e[9] / T, e[40] / T, (e[10] - e[8] - e[9] - e[40]) / T, e[20] / T))
+print("  ACCOUNT total=%.0f waited(events)=%.0f waited(queue)=%.0f busy=%.0f  tiles with events=%.3f  local decisions that disagree=%d" % (e[43] / T, e[41] / T, e[42] / T, (e[43] - e[41] - e[42]) / T, e[44] / T, e[22]))
 
-print("  BUILDER total=%.0f waited=%.0f busy=%.0f" % (e[18] / T, e[17] / T, (e[18] - e[17]) / T))
+print("  BUILDER total=%.0f waited=%.0f (ring %.0f) busy=%.0f" % (e[18] / T, e[17] / T, e[37] / T, (e[18] - e[17]) / T))
+print("  EMIT    total=%.0f waited=%.0f busy=%.0f" % (e[39] / T, e[38] / T, (e[39] - e[38]) / T))
 print("  parser events per tile: stale-truncations=%.2f segments=%.2f hazard-lanes=%.2f (hard %.2f) replays=%.2f" % tuple(e[k] / T for k in (23, 24, 26, 27, 28)))
-print("  hazard lanes per tile by candidate: twin in tile=%.3f in t-1=%.3f in t-2=%.3f | twin far enough=%.3f | resolved as match=%.3f" % tuple(e[k] / T for k in (29, 30, 31, 20, 21)))
+print("  hazard lanes per tile by candidate: twin in tile=%.3f in t-1=%.3f in t-2=%.3f | resolved as match=%.3f" % tuple(e[k] / T for k in (29, 30, 31, 21)))
 print(f"  P6b detail (wave 0): init scan={d[9]} barrier waits={d[10]} read phases={d[11]} write phases={d[15]}")
 names = ["P0 stage", "P1 spec", "P2 dbl", "P3 chain(+flush)", "P4 expand+scan", "P5 pairs+copy", "P5 retry rounds", "P6 jump", "P7/bookkeeping"]
 dt = sum(d[:9])

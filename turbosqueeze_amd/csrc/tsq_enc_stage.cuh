@@ -39,7 +39,8 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4_t lds_u32x4_t;
 
 struct StageCfg {
-    static constexpr uint32_t THREADS = 384;                      // six wavefronts
+    static constexpr uint32_t THREADS = 448;                      // seven wavefronts
+    static constexpr uint32_t EQ = 64, EV_WORDS = 4;              // events between WALK and ACCOUNT
     static constexpr uint32_t Q = 32;
     static constexpr uint32_t ITEM_WORDS = 80;
     static constexpr uint32_t RING = 256;                          // symbol records between BUILDER and EMIT (four batches)
@@ -56,7 +57,8 @@ struct StageCfg {
     static constexpr uint32_t off_rec = off_ring + RING * 4;                   // u32[R * REC_WORDS]
     static constexpr uint32_t off_ctl = off_rec + R * REC_WORDS * 4;           // u32[64]
     static constexpr uint32_t off_f = off_ctl + 256;                           // u8[F_MASK + 1]
-    static constexpr uint32_t off_win = off_f + F_MASK + 1u;                   // u8[WIN + 32]: the ring, its first 32 bytes mirrored at the end
+    static constexpr uint32_t off_evq = off_f + F_MASK + 1u;                   // u32[EQ * EV_WORDS]
+    static constexpr uint32_t off_win = off_evq + EQ * EV_WORDS * 4;           // u8[WIN + 32]: the ring, its first 32 bytes mirrored at the end
     static constexpr uint32_t total = off_win + WIN + 32;
     static constexpr uint32_t total_lean = off_win;                            // without the window: two blocks fit one CU
 };
@@ -67,6 +69,10 @@ struct StageCfg {
 //                          7 spanword  8 candidate | nibble << 24  9 orbit halt  10,11 orbit mask
 // spanword: natural span (bits 0..7) | hard (8) | has a twin (9) | certain match (10) | near twin (11) | common prefix (16..23)
 enum : uint32_t { kAH = 0, kATin = 1, kATp1 = 3, kATp2 = 5, kASpan = 7, kALane = 8, kANx = 9, kAOrb = 10 };
+// events between WALK and ACCOUNT, and their ctl words (10 events produced, 11 consumed, 12 queries answered, 13 the answer,
+// 14 the tile ACCOUNT works on: the tiles before it are accounted)
+enum : uint32_t { kEvSeg = 1, kEvHaz = 2, kEvEnd = 3 };
+enum : uint32_t { kCtlEvHead = 10, kCtlEvTail = 11, kCtlReplies = 12, kCtlReplyValue = 13, kCtlAccounted = 14 };
 
 // Instrumented builds time only the spin loops (and only when they actually spin): s_memtime costs a few
 // hundred cycles, so finer timing distorts the pipeline it measures.  busy = total - waited.
@@ -140,8 +146,9 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
     TSQ_BEGIN();
     uint4 w_next = ld128z(src, lane, avail);
     for (uint32_t t = 0; t < n_tiles; ++t) {
-        // the slot of tile t-R is free once the parser has finished tile t-R+2 (it reads the words of two tiles back)
+        // the slot of tile t-R is free once WALK has finished tile t-R+2 (it reads the words of two tiles back) and ACCOUNT is past tile t-R
         if (t + 3u > StageCfg::R && !stage_wait(ctl, 5, t + 3u - StageCfg::R, 0)) break;
+        if (t + 1u > StageCfg::R && !stage_wait(ctl, kCtlAccounted, t + 1u - StageCfg::R, 0)) break;
         const uint32_t p = (t << 6) + lane;
         const uint4 w16 = w_next;
         w_next = ld128z(src, (uint64_t)p + 64u, avail);    // the next tile's words: this wave's only global access, a full iteration ahead
@@ -470,53 +477,60 @@ __device__ __forceinline__ uint32_t s_msb64(uint64_t x)                   // x !
 __device__ __forceinline__ uint32_t s_lsb64(uint64_t x)                   // x != 0
 { uint32_t d; asm("s_ff1_i32_b64 %0, %1" : "=s"(d) : "s"(x)); return d; }
 
-// -------------------------------------------------------------------------------------------- PARSER
-// All parse state lives in uniform 32-bit integers (flags as 0/1, not bool: a bool that crosses a branch
-// becomes a 64-bit lane mask and costs VALU round trips), and the common paths are straight-line selects:
-// for a single wavefront a uniform branch costs more than the few instructions it skips.
+// ------------------------------------------------------------------------------------ WALK + ACCOUNT
+// The serial part of the parse, on two wavefronts.
+//
+//   WALK     decides which positions the parse VISITS -- the only thing MATCH (the position table) and the next tile need.  Per tile:
+//            the orbit of the actual entry lane (three v_readlane), the check for visited twins, and for a hazard lane its candidate
+//            (the most recent visited twin, or the gathered one) and common prefix.  A hazard whose candidate lies far enough back
+//            that the pair origin cannot matter is decided on the spot; the others (candidate closer than kDMin, block tail) are
+//            QUERIES: ACCOUNT, which holds the symbol state, answers with the next position.
+//   ACCOUNT  the symbol accounting of tsq_encode.cpp:93-95,113-115,157-159 -- symbol count, pair origin, pending literal, the
+//            reference-time origin inside literal runs -- in O(1) per segment from its masks, the exact scalar decision of every
+//            hazard lane (tsq_encode.cpp:100,139-145), and the items for the BUILDER.  It trails WALK by an event or two.
+//
+// Events (8 words each, a single-producer/single-consumer ring in LDS): kEvSeg {base, V lo, V hi}: the lanes of tile `base` visited
+// by one hazard-free stretch of the orbit; kEvHaz {i, candidate, k | twin << 8 | local << 9}: one hazard lane; kEvEnd.
+
 template <bool EXT, bool WINDOW>
-__device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail, uint32_t n, lds_u8_t* lds, uint32_t lane)
+__device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, uint32_t n, lds_u8_t* lds, uint32_t lane)
 {
-    volatile lds_u32_t* queue = (volatile lds_u32_t*)(lds + StageCfg::off_queue);
+    volatile lds_u32_t* evq = (volatile lds_u32_t*)(lds + StageCfg::off_evq);
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
+    constexpr uint32_t kDMin = EXT ? 128u : 64u;
+    const uint32_t tail_from = uniform(n >= 5u ? n - 5u : 0u);
 
-    uint32_t head = 0, tail_seen = 0;  // tail_seen: last value read of the builder's progress (re-read only when the queue looks full)
-    uint32_t v = 1, nsym = 0, origin = 0, lit_from = 0;
-    uint32_t am = 0;                   // 1 right after a match (tsq_encode.cpp:160-187), 0 inside a literal run
-    uint32_t run0 = 0, origin_r0 = 0, odd_r0 = 0;   // where the current literal run started, the pair origin and symbol parity then
-    uint32_t done = 0;
+    uint32_t ev_head = 0, ev_tail_seen = 0, n_query = 0;
+    uint32_t v = 1, done = 0;
+    uint32_t last_m = 0;                 // where the most recent match symbol starts: no pair origin lies before it
     uint64_t vall_p1 = 0, vall_p2 = 0;   // visited lanes of the two previous tiles
 #ifdef TSQ_STATS
     unsigned long long st_[32] = {0};
 #endif
 
-    auto slot_begin = [&]() -> volatile lds_u32_t* {
-        if (head - tail_seen >= StageCfg::Q) {
+    auto ev_push = [&](uint32_t kind, uint32_t a, uint32_t b, uint32_t c) {
+        if (ev_head - ev_tail_seen >= StageCfg::EQ) {
 #ifdef TSQ_STATS
             const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
 #endif
-            while (head - tail_seen >= StageCfg::Q) {
-                tail_seen = uniform(__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                if (head - tail_seen >= StageCfg::Q) __builtin_amdgcn_s_sleep(2);
+            while (ev_head - ev_tail_seen >= StageCfg::EQ) {
+                ev_tail_seen = uniform(__hip_atomic_load(&ctl[kCtlEvTail], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (ev_head - ev_tail_seen >= StageCfg::EQ) __builtin_amdgcn_s_sleep(1);
             }
 #ifdef TSQ_STATS
             st_[9] += __builtin_amdgcn_s_memtime() - w0_;
 #endif
         }
-        return queue + (head % StageCfg::Q) * StageCfg::ITEM_WORDS;
-    };
-    auto slot_publish = [&]() {
+        volatile lds_u32_t* e = evq + (ev_head % StageCfg::EQ) * StageCfg::EV_WORDS;
+        uint32_t hv = kind;
+        asm volatile("v_writelane_b32 %0, %1, 1" : "+v"(hv) : "s"(a));
+        asm volatile("v_writelane_b32 %0, %1, 2" : "+v"(hv) : "s"(b));
+        asm volatile("v_writelane_b32 %0, %1, 3" : "+v"(hv) : "s"(c));
+        if (lane < 4u) e[lane] = hv;
         TSQ_LDS_RELEASE();
-        head++;
-        if (lane == 0) __hip_atomic_store(&ctl[0], head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    auto push = [&](uint32_t record, uint32_t origin_if_pair_closes) {
-        volatile lds_u32_t* it = slot_begin();
-        if (lane == 0) { it[0] = kItemSym; it[4] = nsym; it[9] = record; }
-        slot_publish();
-        nsym++;
-        if ((nsym & 1u) == 0u) origin = origin_if_pair_closes;
+        ev_head++;
+        __hip_atomic_store(&ctl[kCtlEvHead], ev_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     // the 16 input bytes at a position of tiles t-2 .. t, from the tile records (one LDS address for the whole wave)
     auto words_at = [&](uint32_t pos) -> uint4 {
@@ -530,9 +544,6 @@ __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail,
         const uint32_t base = t << 6;
         uint64_t vall = 0;
         if (v < base + 64u) {
-            // ---- the tile's record
-            REG_BEGIN(0); REG_END(0);
-            REG_BEGIN(1);
             // (the serial stage polls without sleeping: a wake-up from s_sleep costs it up to 64 cycles per hand-off)
             if (!stage_ready(ctl, 4, t + 1u)) {
 #ifdef TSQ_STATS
@@ -553,91 +564,19 @@ __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail,
             const uint32_t tp1_lo = arr[kATp1 * 64], tp1_hi = arr[(kATp1 + 1) * 64];
             const uint32_t tp2_lo = arr[kATp2 * 64], tp2_hi = arr[(kATp2 + 1) * 64];
             const uint64_t hard = __ballot((spanword & 0x100u) != 0u);
-            const uint64_t certain_m = __ballot((spanword & 0x400u) != 0u);
             const uint64_t near_m = __ballot((spanword & 0x800u) != 0u);
+            const uint64_t certain_m = __ballot((spanword & 0x400u) != 0u);
+            const uint32_t span_nat = spanword & 0xFFu;
+            uint64_t Vacc = 0;                   // visited lanes not yet handed to ACCOUNT
             // a twin visited in the two previous tiles: fixed for the whole tile (kept per lane, it joins the in-tile test)
             const uint32_t prev_hit = (tp1_lo & (uint32_t)vall_p1) | (tp1_hi & (uint32_t)(vall_p1 >> 32)) |
                                       (tp2_lo & (uint32_t)vall_p2) | (tp2_hi & (uint32_t)(vall_p2 >> 32));
-            const uint32_t span_nat = spanword & 0xFFu;
             const uint32_t k0 = (spanword >> 16) & 0xFFu;
             const uint32_t cand0 = lane_word & 0xFFFFFFu;
 
-            // The tile's symbols go to the builder as ONE item: visited lanes, which of them are matches, and the
-            // per-lane candidate|nibble words -- the builder derives literal chunks, symbol indices and pair origins
-            // from the masks.  Hazard lanes resolved below patch the masks; only the rare outcomes the masks cannot
-            // express (a literal closed in front of a match that then fails, the block tail) are pushed explicitly,
-            // after flushing what is pending.
-            uint64_t Vt = 0, Mt = 0;
-            uint32_t lw = lane_word;
-            uint32_t e_nsym = nsym, e_origin = origin, e_lit_from = lit_from;
-            auto flush_pending = [&]() {
-                if (Vt != 0ull) {
-                    volatile lds_u32_t* it = slot_begin();
-                    // the nine header words, one per lane, in one store
-                    uint32_t hv = kItemSeg;
-                    asm volatile("v_writelane_b32 %0, %1, 1" : "+v"(hv) : "s"(base));
-                    asm volatile("v_writelane_b32 %0, %1, 2" : "+v"(hv) : "s"((uint32_t)Vt));
-                    asm volatile("v_writelane_b32 %0, %1, 3" : "+v"(hv) : "s"((uint32_t)(Vt >> 32)));
-                    asm volatile("v_writelane_b32 %0, %1, 4" : "+v"(hv) : "s"(e_nsym));
-                    asm volatile("v_writelane_b32 %0, %1, 5" : "+v"(hv) : "s"(e_origin));
-                    asm volatile("v_writelane_b32 %0, %1, 6" : "+v"(hv) : "s"(e_lit_from));
-                    asm volatile("v_writelane_b32 %0, %1, 7" : "+v"(hv) : "s"((uint32_t)Mt));
-                    asm volatile("v_writelane_b32 %0, %1, 8" : "+v"(hv) : "s"((uint32_t)(Mt >> 32)));
-                    if (lane < 9u) it[lane] = hv;
-                    it[16 + lane] = lw;
-                    slot_publish();
-                }
-                Vt = 0; Mt = 0;
-            };
-
-            // exact effect of a segment on the parse state, one step per literal RUN or match (used when a run
-            // reaches a 16-byte chunk boundary inside the segment: incompressible data, runs of equal bytes)
-            auto replay_segment = [&](uint64_t V) {
-                const uint64_t N = V & ~certain_m;
-                const uint32_t Le = msb64(V);
-                uint32_t L = lsb64(V);
-                while (L <= Le) {
-                    const uint32_t q = base + L;
-                    if ((N >> L) & 1ull) {                       // a run of literal bytes starting at lane L
-                        const uint32_t len = ones_from(N, L);
-                        if (am) { run0 = q; origin_r0 = origin; odd_r0 = nsym & 1u; am = 0; }
-                        const uint32_t full = (q + len - lit_from) >> 4;            // 16-byte chunks that complete inside the run
-                        if (full) {
-                            nsym += full;
-                            if ((nsym & 1u) == 0u) origin = lit_from + 16u * full;   // the last chunk closed a pair
-                            else if (full >= 2u) origin = lit_from + 16u * (full - 1u);   // the one before it did
-                            lit_from += 16u * full;
-                        }
-                        L += len;
-                    } else {                                     // a certain match
-                        const uint32_t sp = rdlane(span_nat, L);
-                        if (lit_from < q) { nsym++; if ((nsym & 1u) == 0u) origin = q; }
-                        nsym++;
-                        if ((nsym & 1u) == 0u) origin = q + sp;
-                        lit_from = q + sp;
-                        am = 1;
-                        L += sp;
-                    }
-                }
-            };
             uint32_t L = v - base;
-            REG_END(1);
-            // Costs that shape this loop (one wavefront, measured: tools/micro/issue_rate.hip): ALU instruction 4.5 cycles,
-            // branch ~20 cycles taken OR NOT, a VALU result read by the SALU (readlane, ballot) +20 cycles.  So: selects
-            // instead of branches, rare cases folded into one test, lane reads batched.
-#ifdef TSQ_STATS
-            unsigned long long back_ = 0;
-#endif
-            while (done == 0u) {
-#ifdef TSQ_STATS
-                if (18 == TSQ_REGION && back_) { st_[11] += __builtin_amdgcn_s_memtime() - back_; st_[12] += 1; }
-#endif
-                REG_BEGIN(2);
+            for (;;) {
                 const uint32_t L0 = L;                                           // < 64
-                {
-                    const uint32_t fresh = s_nz64(Vt) ^ 1u;
-                    e_nsym = s_sel(fresh, nsym, e_nsym); e_origin = s_sel(fresh, origin, e_origin); e_lit_from = s_sel(fresh, lit_from, e_lit_from);
-                }
                 // the orbit from L0: halts on a hard lane or past the tile (nothing at all if L0 itself is hard)
                 const uint32_t o_lo = rdlane(orb_lo, L0), o_hi = rdlane(orb_hi, L0), o_nx = rdlane(nx, L0);
                 const uint32_t entry_ok = ((uint32_t)(hard >> L0) & 1u) ^ 1u;
@@ -669,95 +608,35 @@ __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail,
                     TSQ_CNT(23, trunc);
                 }
                 TSQ_CNT(24, 1);
-                REG_END(2);
-                REG_BEGIN(3);
-                // ---- the segment's effect on the parse state, O(1) from its masks.  `dsym` symbols close (matches and
-                //      the literal runs in front of them); the state afterwards hangs on the last match.
-                const uint64_t M = V & certain_m, N = V ^ M;
                 {
-                    const uint32_t nonempty = s_nz64(V), has_m = s_nz64(M);
-                    const uint32_t Le = s_msb64(V | 1ull), Lm = s_msb64(M | 1ull);
-                    const uint32_t first_isN = (uint32_t)(N >> L0) & 1u;                // L0 is the lowest lane of V
-                    uint64_t r = N & (N >> 1); r &= r >> 2; r &= r >> 4; r &= r >> 8;     // a literal run of 16 or more inside
-                    const uint32_t run_end = base + s_sel(has_m, s_lsb64(M | (1ull << 63)), Le + 1u);
-                    const uint32_t chunk = s_ge(run_end - lit_from, 16u) & first_isN;     // the entry run completes a 16-byte chunk
-                    if (__builtin_expect(s_nz64(r) | chunk, 0)) { TSQ_CNT(28, 1); replay_segment(V); }
-                    else {
-                        const uint32_t e_pos = base + L0, lm_pos = base + Lm, endm = lm_pos + rdlane(span_nat, Lm);
-                        const uint32_t last_m = s_eq(Le, Lm) & has_m;
-                        const uint32_t pre = s_lt(lit_from, e_pos) & (first_isN ^ 1u);      // a pending literal closes in front of an entry match
-                        const uint32_t dsym = (uint32_t)__builtin_popcountll(M) + (uint32_t)__builtin_popcountll(M & (N << 1)) + pre;
-                        const uint32_t nsym_n = nsym + s_sel(has_m, dsym, 0u);
-                        const uint32_t origin_n = s_sel(has_m, s_sel(nsym_n & 1u, lm_pos, endm), origin);
-                        const uint32_t new_run = s_sel(has_m, last_m ^ 1u, am & nonempty);   // a literal run starts inside / at the entry of the segment
-                        run0 = s_sel(new_run, s_sel(has_m, endm, e_pos), run0);
-                        origin_r0 = s_sel(new_run, origin_n, origin_r0);
-                        odd_r0 = s_sel(new_run, nsym_n & 1u, odd_r0);
-                        lit_from = s_sel(has_m, endm, lit_from);
-                        am = s_sel(nonempty, last_m, am);
-                        nsym = nsym_n;
-                        origin = origin_n;
-                    }
+                    const uint64_t M = V & certain_m;
+                    last_m = s_sel(s_nz64(M), base + s_msb64(M | 1ull), last_m);
                 }
-                REG_END(3);
-                REG_BEGIN(17);
-                Vt |= V; Mt |= M;
+                Vacc |= V;
                 vall |= V;
-                if (L >= 64u) { v = base + L; REG_END(17); break; }
-                REG_END(17);
-                REG_BEGIN(4);
+                if (L >= 64u) { v = base + L; break; }
                 TSQ_CNT(26, 1); TSQ_CNT(27, ((hard >> L) & 1ull) ? 1 : 0);
+                // ---- one hazard lane (hard, or with a visited twin): its candidate and common prefix
+                const uint32_t i = base + L;
+                uint32_t cand = rdlane(cand0, L);
+                uint32_t k = rdlane(k0, L);
+                uint32_t twin_cand = 0;
                 {
-                    // ---- exact scalar resolution of one hazard lane (hard, or with a visited twin)
-                    const uint32_t i = base + L;
-                    const uint64_t bit = 1ull << L;
-                    uint32_t cand = rdlane(cand0, L);
-                    uint32_t k = rdlane(k0, L);
-                    uint32_t twin_cand = 0;
-                    {
-                        // visited twins of lane L: in this tile (before L) and in the two previous tiles;
-                        // the most recent one is the candidate
-                        const uint64_t in_tile = ((uint64_t)rdlane(tin_lo, L) | ((uint64_t)rdlane(tin_hi, L) << 32)) & vall;
-                        const uint64_t in_p1 = ((uint64_t)rdlane(tp1_lo, L) | ((uint64_t)rdlane(tp1_hi, L) << 32)) & vall_p1;
-                        const uint64_t in_p2 = ((uint64_t)rdlane(tp2_lo, L) | ((uint64_t)rdlane(tp2_hi, L) << 32)) & vall_p2;
-                        if (in_tile | in_p1 | in_p2) {
-                            const uint64_t pick = in_tile ? in_tile : in_p1 ? in_p1 : in_p2;
-                            const uint32_t back = in_tile ? 0u : in_p1 ? 64u : 128u;
-                            cand = base - back + msb64(pick);
-                            k = uniform(prefix16(words_at(i), words_at(cand)));
-                            twin_cand = 1;
-                            TSQ_CNT(17, in_tile ? 1 : 0); TSQ_CNT(18, (!in_tile && in_p1) ? 1 : 0); TSQ_CNT(19, (!in_tile && !in_p1) ? 1 : 0);
-                        }
-                    }
-                    vall |= bit;
-                    const uint32_t e4 = s_ge(k, 4u);
-                    const uint32_t f = (i - 1u - run0) >> 5;
-                    const uint32_t o_ref = s_sel(f, s_sel(odd_r0, run0 + 32u * f - 16u, run0 + 32u * f), origin_r0);
-                    // the first test (tsq_encode.cpp:80,100 in a literal run; :170 right after a match)
-                    const uint32_t pass = e4 & s_sel(am, s_lt(i, n - 5u) & s_offset_ok(origin - cand), s_offset_ok(o_ref - cand));
-                    if (__builtin_expect(!(i < n), 0)) {
-                        // the end of the block (tsq_encode.cpp:120,173)
-                        if (am == 0u || pass) {
-                            flush_pending();
-                            if (am == 0u && i > lit_from) { push(rec_literal(lit_from, i - lit_from), i); lit_from = i; }
-                        }
-                        am = 0;
-                        done = 1;
-                    } else if (pass == 0u) {
-                        // no match here: the lane is a literal byte, either the first of a new run or one more of the current one
-                        // (where a full 16-byte chunk may close: the builder sees that in the masks)
-                        Vt |= bit;
-                        v = i + 1u;
-                        const uint32_t full = s_eq(v - lit_from, 16u) & (am ^ 1u);
-                        run0 = s_sel(am, i, run0); origin_r0 = s_sel(am, origin, origin_r0); odd_r0 = s_sel(am, nsym & 1u, odd_r0);
-                        nsym += full;
-                        origin = s_sel(full & ((nsym & 1u) ^ 1u), v, origin);
-                        lit_from = s_sel(am, i, s_sel(full, v, lit_from));
-                        am = 0;
-                    } else {
-                        const uint32_t pend = s_lt(lit_from, i) & (am ^ 1u);   // a pending literal closes in front of the match (tsq_encode.cpp:103-118)
-                        if (EXT && twin_cand) {
-                            // (the bytes behind the first 16 come from the input window ring when SCAN has put everything up to i + 64 there)
+                    // visited twins of lane L: in this tile (before L) and in the two previous tiles;
+                    // the most recent one is the candidate
+                    const uint64_t in_tile = ((uint64_t)rdlane(tin_lo, L) | ((uint64_t)rdlane(tin_hi, L) << 32)) & vall;
+                    const uint64_t in_p1 = ((uint64_t)rdlane(tp1_lo, L) | ((uint64_t)rdlane(tp1_hi, L) << 32)) & vall_p1;
+                    const uint64_t in_p2 = ((uint64_t)rdlane(tp2_lo, L) | ((uint64_t)rdlane(tp2_hi, L) << 32)) & vall_p2;
+                    if (in_tile | in_p1 | in_p2) {
+                        const uint64_t pick = in_tile ? in_tile : in_p1 ? in_p1 : in_p2;
+                        const uint32_t back = in_tile ? 0u : in_p1 ? 64u : 128u;
+                        cand = base - back + msb64(pick);
+                        k = uniform(prefix16(words_at(i), words_at(cand)));
+                        twin_cand = 1;
+                        TSQ_CNT(17, in_tile ? 1 : 0); TSQ_CNT(18, (!in_tile && in_p1) ? 1 : 0); TSQ_CNT(19, (!in_tile && !in_p1) ? 1 : 0);
+                        if (EXT && k >= 16u) {
+                            // matches longer than 16 (tsq_encode.cpp:280-290).  (The bytes behind the first 16 come from the input window
+                            // ring when SCAN has put everything up to i + 64 there.)
                             const bool in_window = WINDOW && i - cand <= 65536u &&
                                                    uniform(__hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= t + 2u;
                             auto win16 = [&](int32_t wi) -> uint4 {
@@ -777,59 +656,322 @@ __device__ __forceinline__ void stage_parser(const uint8_t* src, uint64_t avail,
                                 if (add < 16u) break;
                             }
                         }
-                        // the pair origin the match sees: after the pending literal, if there is one
-                        const uint32_t nsym1 = nsym + pend;
-                        const uint32_t origin1 = s_sel(pend & ((nsym1 & 1u) ^ 1u), i, origin);
-                        const uint32_t room = origin1 - cand;
-                        k = s_sel(s_lt(room, k), room - 1u, k);
-                        if (__builtin_expect(s_lt(k, 4u) | (s_offset_ok(room) ^ 1u), 0)) {
-                            // the literal was closed and the match then fails: the masks cannot say that
-                            if (pend) {
-                                flush_pending();
-                                push(rec_literal(lit_from, i - lit_from), i);
-                                e_nsym = nsym; e_origin = origin; e_lit_from = i;
-                            }
-                            Vt |= bit;
-                            am = 0; run0 = i; origin_r0 = origin; odd_r0 = nsym & 1u; lit_from = i; v = i + 1u;
-                        } else {
-                            const uint32_t m = length_nibble(k);
-                            const uint32_t ni = i + nibble_span(m);
-                            nsym = nsym1 + 1u;
-                            origin = s_sel(nsym & 1u, origin1, ni);
-                            TSQ_CNT(21, 1);
-                            Vt |= bit; Mt |= bit;
-                            lw = lane == L ? (cand | (m << 24)) : lw;
-                            am = 1;
-                            lit_from = ni;
-                            v = ni;
-                        }
                     }
                 }
-                L = v - base;
-                REG_END(4);
+                vall |= 1ull << L;
+                // The lane decides like a certain lane when no pair origin the reference could use here lies closer to the candidate than
+                // the match is long (tsq_encode.cpp:100,139-145: offset = origin - candidate must reach 4 and the match length): every
+                // such origin -- the one of the scan-time test and the one after the pending literal -- is at or behind the start of the
+                // most recent match symbol.  WALK then moves on at once and ACCOUNT patches the lane into the tile's masks.  Everything
+                // else (a candidate right behind the last match, the block tail) waits for ACCOUNT's exact answer.
+                const uint32_t need = k < 4u ? 4u : k;
+                const uint32_t local = s_ge(last_m, cand + need) & s_lt(i, tail_from) & s_lt(i - cand, 0xFF00u);
+                if (local) {
+                    ev_push(kEvHaz, i, cand, k | (twin_cand << 8) | (1u << 9));
+                    const uint32_t m = length_nibble(need);
+                    const uint32_t is_m = s_ge(k, 4u);
+                    v = s_sel(is_m, i + nibble_span(m), i + 1u);
+                    last_m = s_sel(is_m, i, last_m);
+                    Vacc |= 1ull << L;
+                } else {
+                    if (Vacc != 0ull) { ev_push(kEvSeg, base, (uint32_t)Vacc, (uint32_t)(Vacc >> 32)); Vacc = 0; }
+                    ev_push(kEvHaz, i, cand, k | (twin_cand << 8));
+                    n_query++;
+                    TSQ_CNT(20, 1);
 #ifdef TSQ_STATS
-                if (18 == TSQ_REGION) back_ = __builtin_amdgcn_s_memtime();
+                    const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
 #endif
-                if (L >= 64u) break;
+                    while (!stage_ready(ctl, kCtlReplies, n_query)) {}
+#ifdef TSQ_STATS
+                    st_[10] += __builtin_amdgcn_s_memtime() - w0_;
+#endif
+                    const uint32_t r = uniform(__hip_atomic_load(&ctl[kCtlReplyValue], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    v = r & 0x7FFFFFFFu;
+                    done = r >> 31;
+                    last_m = s_sel(s_ge(v - i, 4u), i, last_m);
+                }
+                L = v - base;
+                if (L >= 64u || done != 0u) break;
             }
-            REG_BEGIN(5);
-            flush_pending();
-            REG_END(5);
+            if (Vacc != 0ull) ev_push(kEvSeg, base, (uint32_t)Vacc, (uint32_t)(Vacc >> 32));
         }
         // ---- hand the tile's visited mask to MATCH (it commits the table) and move on
-        REG_BEGIN(6);
         {
             const uint32_t slot = 16u + 2u * (t & 7u);
             if (lane < 2u) __hip_atomic_store(&ctl[slot + lane], lane ? (uint32_t)(vall >> 32) : (uint32_t)vall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         stage_publish(ctl, 5, t + 1u, lane);
         vall_p2 = vall_p1; vall_p1 = vall;
-        REG_END(6);
     }
 #ifdef TSQ_STATS
-    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[8] = st_[8]; g_enc_stats[9] = st_[9]; g_enc_stats[10] = TSQ_TOTAL(); g_enc_stats[11] = st_[11]; g_enc_stats[12] = st_[12]; g_enc_stats[15] = st_[15]; g_enc_stats[16] = nsym; for (int q = 22; q < 29; ++q) g_enc_stats[q] = st_[q]; g_enc_stats[29] = st_[17]; g_enc_stats[30] = st_[18]; g_enc_stats[31] = st_[19]; g_enc_stats[20] = st_[20]; g_enc_stats[21] = st_[21]; }
+    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[8] = st_[8]; g_enc_stats[9] = st_[9]; g_enc_stats[10] = TSQ_TOTAL(); g_enc_stats[15] = st_[15]; for (int q = 23; q < 28; ++q) g_enc_stats[q] = st_[q]; g_enc_stats[29] = st_[17]; g_enc_stats[30] = st_[18]; g_enc_stats[31] = st_[19]; g_enc_stats[20] = st_[20]; g_enc_stats[40] = st_[10]; }
 #endif
-    if (lane == 0) __hip_atomic_store(&ctl[6], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&ctl[6], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    ev_push(kEvEnd, 0u, 0u, 0u);
+}
+
+// All symbol state lives in uniform 32-bit integers (flags as 0/1, not bool: a bool that crosses a branch
+// becomes a 64-bit lane mask and costs VALU round trips), and the common paths are straight-line selects:
+// for a single wavefront a uniform branch costs more than the few instructions it skips.
+__device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_t lane)
+{
+    volatile lds_u32_t* queue = (volatile lds_u32_t*)(lds + StageCfg::off_queue);
+    volatile lds_u32_t* evq = (volatile lds_u32_t*)(lds + StageCfg::off_evq);
+    volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
+    lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
+
+    uint32_t head = 0, tail_seen = 0;  // tail_seen: last value read of the builder's progress (re-read only when the queue looks full)
+    uint32_t nsym = 0, origin = 0, lit_from = 0;
+    uint32_t am = 0;                   // 1 right after a match (tsq_encode.cpp:160-187), 0 inside a literal run
+    uint32_t run0 = 0, origin_r0 = 0, odd_r0 = 0;   // where the current literal run started, the pair origin and symbol parity then
+    uint32_t ev_tail = 0, n_reply = 0;
+#ifdef TSQ_STATS
+    unsigned long long st_[32] = {0};
+#endif
+
+    auto slot_begin = [&]() -> volatile lds_u32_t* {
+        if (head - tail_seen >= StageCfg::Q) {
+#ifdef TSQ_STATS
+            const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
+#endif
+            while (head - tail_seen >= StageCfg::Q) {
+                tail_seen = uniform(__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (head - tail_seen >= StageCfg::Q) __builtin_amdgcn_s_sleep(2);
+            }
+#ifdef TSQ_STATS
+            st_[9] += __builtin_amdgcn_s_memtime() - w0_;
+#endif
+        }
+        return queue + (head % StageCfg::Q) * StageCfg::ITEM_WORDS;
+    };
+    auto slot_publish = [&]() {
+        TSQ_LDS_RELEASE();
+        head++;
+        __hip_atomic_store(&ctl[0], head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto push = [&](uint32_t record, uint32_t origin_if_pair_closes) {
+        volatile lds_u32_t* it = slot_begin();
+        if (lane == 0) { it[0] = kItemSym; it[4] = nsym; it[9] = record; }
+        slot_publish();
+        nsym++;
+        if ((nsym & 1u) == 0u) origin = origin_if_pair_closes;
+    };
+
+    // the tile the events at hand belong to: its masks and per-lane words
+    uint32_t base = 0xFFFFFFFFu;
+    uint32_t span_nat = 0, lw = 0;
+    uint64_t certain_m = 0;
+    // The tile's symbols go to the builder as ONE item: visited lanes, which of them are matches, and the
+    // per-lane candidate|nibble words -- the builder derives literal chunks, symbol indices and pair origins
+    // from the masks.  Hazard lanes patch the masks; only the rare outcomes the masks cannot
+    // express (a literal closed in front of a match that then fails, the block tail) are pushed explicitly,
+    // after flushing what is pending.
+    uint64_t Vt = 0, Mt = 0;
+    uint32_t e_nsym = 0, e_origin = 0, e_lit_from = 0;
+    auto flush_pending = [&]() {
+        if (Vt != 0ull) {
+            volatile lds_u32_t* it = slot_begin();
+            // the nine header words, one per lane, in one store
+            uint32_t hv = kItemSeg;
+            asm volatile("v_writelane_b32 %0, %1, 1" : "+v"(hv) : "s"(base));
+            asm volatile("v_writelane_b32 %0, %1, 2" : "+v"(hv) : "s"((uint32_t)Vt));
+            asm volatile("v_writelane_b32 %0, %1, 3" : "+v"(hv) : "s"((uint32_t)(Vt >> 32)));
+            asm volatile("v_writelane_b32 %0, %1, 4" : "+v"(hv) : "s"(e_nsym));
+            asm volatile("v_writelane_b32 %0, %1, 5" : "+v"(hv) : "s"(e_origin));
+            asm volatile("v_writelane_b32 %0, %1, 6" : "+v"(hv) : "s"(e_lit_from));
+            asm volatile("v_writelane_b32 %0, %1, 7" : "+v"(hv) : "s"((uint32_t)Mt));
+            asm volatile("v_writelane_b32 %0, %1, 8" : "+v"(hv) : "s"((uint32_t)(Mt >> 32)));
+            if (lane < 9u) it[lane] = hv;
+            it[16 + lane] = lw;
+            slot_publish();
+        }
+        Vt = 0; Mt = 0;
+    };
+    // exact effect of a segment on the symbol state, one step per literal RUN or match (used when a run
+    // reaches a 16-byte chunk boundary inside the segment: incompressible data, runs of equal bytes)
+    auto replay_segment = [&](uint64_t V) {
+        const uint64_t N = V & ~certain_m;
+        const uint32_t Le = msb64(V);
+        uint32_t L = lsb64(V);
+        while (L <= Le) {
+            const uint32_t q = base + L;
+            if ((N >> L) & 1ull) {                       // a run of literal bytes starting at lane L
+                const uint32_t len = ones_from(N, L);
+                if (am) { run0 = q; origin_r0 = origin; odd_r0 = nsym & 1u; am = 0; }
+                const uint32_t full = (q + len - lit_from) >> 4;            // 16-byte chunks that complete inside the run
+                if (full) {
+                    nsym += full;
+                    if ((nsym & 1u) == 0u) origin = lit_from + 16u * full;   // the last chunk closed a pair
+                    else if (full >= 2u) origin = lit_from + 16u * (full - 1u);   // the one before it did
+                    lit_from += 16u * full;
+                }
+                L += len;
+            } else {                                     // a certain match
+                const uint32_t sp = rdlane(span_nat, L);
+                if (lit_from < q) { nsym++; if ((nsym & 1u) == 0u) origin = q; }
+                nsym++;
+                if ((nsym & 1u) == 0u) origin = q + sp;
+                lit_from = q + sp;
+                am = 1;
+                L += sp;
+            }
+        }
+    };
+
+    TSQ_BEGIN();
+    for (;;) {
+        if (!stage_ready(ctl, kCtlEvHead, ev_tail + 1u)) {
+#ifdef TSQ_STATS
+            const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
+#endif
+            while (!stage_ready(ctl, kCtlEvHead, ev_tail + 1u)) __builtin_amdgcn_s_sleep(1);
+#ifdef TSQ_STATS
+            st_[8] += __builtin_amdgcn_s_memtime() - w0_;
+#endif
+        }
+        uint32_t kind, ea, eb, ec;
+        {
+            volatile lds_u32_t* e = evq + (ev_tail % StageCfg::EQ) * StageCfg::EV_WORDS;
+            const uint32_t w = e[lane & 3u];
+            kind = rdlane(w, 0); ea = rdlane(w, 1); eb = rdlane(w, 2); ec = rdlane(w, 3);
+            ev_tail++;
+            __hip_atomic_store(&ctl[kCtlEvTail], ev_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (kind == kEvEnd) break;
+        const uint32_t ev_base = ea & ~63u;
+        if (ev_base != base) {
+            // ---- a new tile: what is pending goes to the builder, then the tile's record
+            flush_pending();
+            base = ev_base;
+            const uint32_t t = base >> 6;
+            volatile lds_u32_t* arr = recs + (t % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::ARR + lane;
+            const uint32_t spanword = arr[kASpan * 64];
+            lw = arr[kALane * 64];
+            span_nat = spanword & 0xFFu;
+            certain_m = __ballot((spanword & 0x400u) != 0u);
+            // (SCAN may reuse the records of the tiles before this one)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __hip_atomic_store(&ctl[kCtlAccounted], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            TSQ_CNT(15, 1);
+        }
+        {
+            const uint32_t fresh = s_nz64(Vt) ^ 1u;
+            e_nsym = s_sel(fresh, nsym, e_nsym); e_origin = s_sel(fresh, origin, e_origin); e_lit_from = s_sel(fresh, lit_from, e_lit_from);
+        }
+        if (kind == kEvSeg) {
+            // ---- the segment's effect on the symbol state, O(1) from its masks.  `dsym` symbols close (matches and
+            //      the literal runs in front of them); the state afterwards hangs on the last match.
+            const uint64_t V = (uint64_t)eb | ((uint64_t)ec << 32);
+            const uint64_t M = V & certain_m, N = V ^ M;
+            const uint32_t L0 = s_lsb64(V);
+            const uint32_t has_m = s_nz64(M);
+            const uint32_t Le = s_msb64(V | 1ull), Lm = s_msb64(M | 1ull);
+            const uint32_t first_isN = (uint32_t)(N >> L0) & 1u;                // L0 is the lowest lane of V
+            uint64_t r = N & (N >> 1); r &= r >> 2; r &= r >> 4; r &= r >> 8;     // a literal run of 16 or more inside
+            const uint32_t run_end = base + s_sel(has_m, s_lsb64(M | (1ull << 63)), Le + 1u);
+            const uint32_t chunk = s_ge(run_end - lit_from, 16u) & first_isN;     // the entry run completes a 16-byte chunk
+            if (__builtin_expect(s_nz64(r) | chunk, 0)) { TSQ_CNT(28, 1); replay_segment(V); }
+            else {
+                const uint32_t e_pos = base + L0, lm_pos = base + Lm, endm = lm_pos + rdlane(span_nat, Lm);
+                const uint32_t last_m = s_eq(Le, Lm) & has_m;
+                const uint32_t pre = s_lt(lit_from, e_pos) & (first_isN ^ 1u);      // a pending literal closes in front of an entry match
+                const uint32_t dsym = (uint32_t)__builtin_popcountll(M) + (uint32_t)__builtin_popcountll(M & (N << 1)) + pre;
+                const uint32_t nsym_n = nsym + s_sel(has_m, dsym, 0u);
+                const uint32_t origin_n = s_sel(has_m, s_sel(nsym_n & 1u, lm_pos, endm), origin);
+                const uint32_t new_run = s_sel(has_m, last_m ^ 1u, am);              // a literal run starts inside / at the entry of the segment
+                run0 = s_sel(new_run, s_sel(has_m, endm, e_pos), run0);
+                origin_r0 = s_sel(new_run, origin_n, origin_r0);
+                odd_r0 = s_sel(new_run, nsym_n & 1u, odd_r0);
+                lit_from = s_sel(has_m, endm, lit_from);
+                am = last_m;
+                nsym = nsym_n;
+                origin = origin_n;
+            }
+            Vt |= V; Mt |= M;
+        } else {
+            const uint32_t i = ea, cand = eb;
+            uint32_t k = ec & 0xFFu;
+            const uint32_t is_query = ((ec >> 9) & 1u) ^ 1u;
+            const uint32_t L = i - base;
+            const uint64_t bit = 1ull << L;
+            if (is_query == 0u) {
+                // ---- a hazard lane WALK has decided: it joins the tile's masks like a certain lane
+                const uint32_t is_m = s_ge(k, 4u);
+                const uint32_t m = length_nibble(k < 4u ? 4u : k);
+                certain_m = s_sel64(is_m, certain_m | bit, certain_m & ~bit);
+                const uint32_t sp = s_sel(is_m, nibble_span(m), 1u);
+                span_nat = lane == L ? sp : span_nat;
+                lw = lane == L ? (cand | (m << 24)) : lw;
+                TSQ_CNT(21, is_m);
+                continue;
+            }
+            // ---- exact scalar resolution of one hazard lane (hard, or with a visited twin)
+            uint32_t v = i + 1u, done = 0;
+            const uint32_t e4 = s_ge(k, 4u);
+            const uint32_t f = (i - 1u - run0) >> 5;
+            const uint32_t o_ref = s_sel(f, s_sel(odd_r0, run0 + 32u * f - 16u, run0 + 32u * f), origin_r0);
+            // the first test (tsq_encode.cpp:80,100 in a literal run; :170 right after a match)
+            const uint32_t pass = e4 & s_sel(am, s_lt(i, n - 5u) & s_offset_ok(origin - cand), s_offset_ok(o_ref - cand));
+            if (__builtin_expect(!(i < n), 0)) {
+                // the end of the block (tsq_encode.cpp:120,173)
+                if (am == 0u || pass) {
+                    flush_pending();
+                    if (am == 0u && i > lit_from) { push(rec_literal(lit_from, i - lit_from), i); lit_from = i; }
+                }
+                am = 0;
+                done = 1;
+            } else if (pass == 0u) {
+                // no match here: the lane is a literal byte, either the first of a new run or one more of the current one
+                // (where a full 16-byte chunk may close: the builder sees that in the masks)
+                Vt |= bit;
+                v = i + 1u;
+                const uint32_t full = s_eq(v - lit_from, 16u) & (am ^ 1u);
+                run0 = s_sel(am, i, run0); origin_r0 = s_sel(am, origin, origin_r0); odd_r0 = s_sel(am, nsym & 1u, odd_r0);
+                nsym += full;
+                origin = s_sel(full & ((nsym & 1u) ^ 1u), v, origin);
+                lit_from = s_sel(am, i, s_sel(full, v, lit_from));
+                am = 0;
+            } else {
+                const uint32_t pend = s_lt(lit_from, i) & (am ^ 1u);   // a pending literal closes in front of the match (tsq_encode.cpp:103-118)
+                // the pair origin the match sees: after the pending literal, if there is one
+                const uint32_t nsym1 = nsym + pend;
+                const uint32_t origin1 = s_sel(pend & ((nsym1 & 1u) ^ 1u), i, origin);
+                const uint32_t room = origin1 - cand;
+                k = s_sel(s_lt(room, k), room - 1u, k);
+                if (__builtin_expect(s_lt(k, 4u) | (s_offset_ok(room) ^ 1u), 0)) {
+                    // the literal was closed and the match then fails: the masks cannot say that
+                    if (pend) {
+                        flush_pending();
+                        push(rec_literal(lit_from, i - lit_from), i);
+                        e_nsym = nsym; e_origin = origin; e_lit_from = i;
+                    }
+                    Vt |= bit;
+                    am = 0; run0 = i; origin_r0 = origin; odd_r0 = nsym & 1u; lit_from = i; v = i + 1u;
+                } else {
+                    const uint32_t m = length_nibble(k);
+                    const uint32_t ni = i + nibble_span(m);
+                    nsym = nsym1 + 1u;
+                    origin = s_sel(nsym & 1u, origin1, ni);
+                    TSQ_CNT(21, 1);
+                    Vt |= bit; Mt |= bit;
+                    lw = lane == L ? (cand | (m << 24)) : lw;
+                    am = 1;
+                    lit_from = ni;
+                    v = ni;
+                }
+            }
+            if (is_query) {
+                __hip_atomic_store(&ctl[kCtlReplyValue], v | (done << 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                TSQ_LDS_RELEASE();
+                n_reply++;
+                __hip_atomic_store(&ctl[kCtlReplies], n_reply, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    flush_pending();
+#ifdef TSQ_STATS
+    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[41] = st_[8]; g_enc_stats[42] = st_[9]; g_enc_stats[43] = TSQ_TOTAL(); g_enc_stats[16] = nsym; g_enc_stats[21] = st_[21]; g_enc_stats[22] = st_[22]; g_enc_stats[28] = st_[28]; g_enc_stats[44] = st_[15]; }
+#endif
     {
         volatile lds_u32_t* it = slot_begin();
         if (lane == 0) { it[0] = kItemEnd; it[4] = nsym; }
@@ -867,9 +1009,10 @@ __global__ __launch_bounds__(StageCfg::THREADS) void enc_stage_kernel(const uint
     }
     __syncthreads();
     lds_u8_t* lds3 = (lds_u8_t*)stage_lds;
-    // Six waves on four SIMDs (wave w runs on SIMD w % 4): the parser shares its SIMD with the emitter, which works once per 64
-    // symbols; ORBIT (which waits a third of its time) shares with the builder.
-    if (role == 0) stage_parser<EXT, WINDOW>(src, avail, n, lds3, lane);
+    // Seven waves on four SIMDs (wave w runs on SIMD w % 4): WALK shares its SIMD with the emitter, which works once per 64
+    // symbols; ORBIT (which waits a third of its time) shares with the builder, MATCH with ACCOUNT.
+    if (role == 0) stage_walk<EXT, WINDOW>(src, avail, n, lds3, lane);
+    else if (role == 6) stage_account(n, lds3, lane);
     else if (role == (TSQ_X2 ? 1 : 3)) stage_scan<WINDOW>(src, avail, n, lds3, lane);
     else if (role == 2) stage_match<EXT, WINDOW>(src, avail, n, table, lds3, lane);
     else if (role == (TSQ_X2 ? 3 : 1)) stage_orbit<EXT>(n, lds3, lane);
