@@ -36,7 +36,7 @@ e = list(enc); d = list(dec)
 T = max(e[15], 1)
 print(f"ENC staged pipeline block0 (tiles parsed={e[15]}, symbols={e[16]}); cycles per tile, busy = total - waited:")
 print("  SCAN    total=%.0f waited(ring)=%.0f busy=%.0f" % (e[1] / T, e[0] / T, (e[1] - e[0]) / T))
-print("          suspect lanes per tile=%.2f (from previous tiles %.2f), group rounds per tile=%.2f" % (e[32] / T, e[34] / T, e[33] / T))
+print("          unsure lanes per tile=%.2f, settle rounds per tile=%.2f, in-tile group rounds per tile=%.2f" % (e[32] / T, e[33] / T, e[34] / T))
 print("  MATCH   total=%.0f waited(scan)=%.0f waited(parser)=%.0f busy=%.0f" % (e[4] / T, e[2] / T, e[3] / T, (e[4] - e[2] - e[3]) / T))
 print("          length-extension rounds per tile=%.2f (from the window ring %.2f)" % (e[36] / T, e[35] / T))
 print("  ORBIT   total=%.0f waited=%.0f busy=%.0f" % (e[7] / T, e[6] / T, (e[7] - e[6]) / T))

@@ -114,6 +114,23 @@ __device__ __forceinline__ bool stage_spin(lds_u32_t* ctl, uint32_t word, uint32
         __builtin_amdgcn_s_sleep(1);
     }
 }
+// The same with the last value seen kept by the caller: a stage that runs behind its producer finds most of its waits
+// satisfied by what it read a few tiles ago and skips the LDS round trip.
+__device__ __forceinline__ bool stage_spin_seen(lds_u32_t* ctl, uint32_t word, uint32_t need, uint32_t& seen)
+{
+    for (;;) {
+        seen = uniform(__hip_atomic_load(&ctl[word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        asm volatile("" ::: "memory");
+        if (seen >= need) return true;
+        if (uniform(__hip_atomic_load(&ctl[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0u) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+#ifdef TSQ_STATS
+#define stage_wait_seen(ctl, word, need, seen, slot) ((seen) >= (need) || [&]() { bool ok_; TSQ_WAITED(slot, ok_ = stage_spin_seen(ctl, word, need, seen)); return ok_; }())
+#else
+#define stage_wait_seen(ctl, word, need, seen, slot) ((seen) >= (need) || stage_spin_seen(ctl, word, need, seen))
+#endif
 #ifdef TSQ_STATS
 #define stage_wait(ctl, word, need, slot) (stage_ready(ctl, word, need) || [&]() { bool ok_; TSQ_WAITED(slot, ok_ = stage_spin(ctl, word, need)); return ok_; }())
 #else
@@ -140,6 +157,7 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
     uint32_t h_m1 = 0xFFFFFFFFu, h_m2 = 0xFFFFFFFFu, h_m3 = 0xFFFFFFFFu;   // hashes of tiles t-1 .. t-3 (per lane)
     uint32_t id = 1;                                    // (t % 3) + 1: which of the three live tiles an owner tag names
     uint32_t wbase = 0;                                 // (t * 64) % WIN
+    uint32_t parsed_seen = 0, accounted_seen = 0;
 #ifdef TSQ_STATS
     unsigned long long st_[32] = {0};
 #endif
@@ -147,23 +165,50 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
     uint4 w_next = ld128z(src, lane, avail);
     for (uint32_t t = 0; t < n_tiles; ++t) {
         // the slot of tile t-R is free once WALK has finished tile t-R+2 (it reads the words of two tiles back) and ACCOUNT is past tile t-R
-        if (t + 3u > StageCfg::R && !stage_wait(ctl, 5, t + 3u - StageCfg::R, 0)) break;
-        if (t + 1u > StageCfg::R && !stage_wait(ctl, kCtlAccounted, t + 1u - StageCfg::R, 0)) break;
+        if (t + 3u > StageCfg::R && !stage_wait_seen(ctl, 5, t + 3u - StageCfg::R, parsed_seen, 0)) break;
+        if (t + 1u > StageCfg::R && !stage_wait_seen(ctl, kCtlAccounted, t + 1u - StageCfg::R, accounted_seen, 0)) break;
         const uint32_t p = (t << 6) + lane;
         const uint4 w16 = w_next;
         w_next = ld128z(src, (uint64_t)p + 64u, avail);    // the next tile's words: this wave's only global access, a full iteration ahead
         const uint32_t h = hash4(w16.x);
         const uint32_t hf = h & StageCfg::OWN_MASK;
         const uint32_t tag = (id << 6) | lane;          // never 0: the image starts zeroed
+        const uint32_t id_m1 = id == 1u ? 3u : id - 1u; // the id of tile t-1 (the third one is tile t-2's)
+        volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
+        volatile lds_u32_t* rec_m1 = recs + ((t + StageCfg::R - 1u) % StageCfg::R) * StageCfg::REC_WORDS;
+        volatile lds_u32_t* rec_m2 = recs + ((t + StageCfg::R - 2u) % StageCfg::R) * StageCfg::REC_WORDS;
         // retire the entries of tile t-3 (same id as tile t) unless a later tile has taken the bucket over
         if (t >= 3u && ((uint32_t)owner[h_m3 & StageCfg::OWN_MASK] >> 6) == id) owner[h_m3 & StageCfg::OWN_MASK] = 0;
-        const uint32_t before = owner[hf];              // non-zero: a lane of tile t-1 or t-2 may have this hash
+        const uint32_t before = owner[hf];              // non-zero: the most recent lane of tile t-1 or t-2 with this folded hash
         owner[hf] = (uint8_t)tag;
+        const uint32_t after = owner[hf];
+        // ---- twins in the two previous tiles (tile t-3 and older are MATCH's business: by then the parser has decided them).
+        // The owner of the bucket, lane q of tile t-1 or t-2, is the MOST RECENT position with this folded hash.  If its hash is
+        // this lane's hash, this lane's twins are q and q's own twins (already exact, by induction): no search.  If it is another
+        // hash (a fold collision: 128 live entries in 32 K buckets), a twin may hide behind it: settled with ballots below.
+        uint64_t twin_p1 = 0, twin_p2 = 0;
+        bool unsure = false;
+        if (__ballot(before != 0u) != 0ull) {
+            const uint32_t q = before & 63u;
+            const bool in_p1 = (before >> 6) == id_m1;
+            volatile lds_u32_t* qa = (in_p1 ? rec_m1 : rec_m2) + StageCfg::ARR + q;
+            const uint32_t hq = qa[kAH * 64];
+            const uint32_t qin_lo = qa[kATin * 64], qin_hi = qa[(kATin + 1) * 64];
+            const uint32_t qp1_lo = qa[kATp1 * 64], qp1_hi = qa[(kATp1 + 1) * 64];
+            const bool same = before != 0u && hq == h;
+            unsure = before != 0u && hq != h;
+            const uint64_t chain = ((uint64_t)qin_lo | ((uint64_t)qin_hi << 32)) | (1ull << q);
+            if (same) {
+                twin_p1 = in_p1 ? chain : 0ull;
+                twin_p2 = in_p1 ? ((uint64_t)qp1_lo | ((uint64_t)qp1_hi << 32)) : chain;
+            }
+        }
         // twins inside the tile: for each lane the mask of EARLIER lanes with the same hash
         uint64_t twin_in = 0, twins_here = 0;
         {
-            uint64_t shared = __ballot(owner[hf] != (uint8_t)tag);
+            uint64_t shared = __ballot(after != (uint8_t)tag);
             while (shared) {
+                TSQ_CNT(22, 1);
                 const uint32_t hl = rdlane(h, lsb64(shared));
                 const uint64_t grp = __ballot(h == hl);
                 if (h == hl) twin_in = grp & below(lane);
@@ -171,10 +216,8 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
                 shared &= ~grp;
             }
         }
-        // twins in the two previous tiles (tile t-3 and older are MATCH's business: by then the parser has decided them)
-        uint64_t twin_p1 = 0, twin_p2 = 0;
         {
-            uint64_t maybe = __ballot(before != 0u);
+            uint64_t maybe = __ballot(unsure);
             TSQ_CNT(20, __builtin_popcountll(maybe));
             while (maybe) {
                 TSQ_CNT(21, 1);
@@ -185,7 +228,6 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
                 maybe &= ~grp_cur;
             }
         }
-        volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
         {
             u32x4_t v; v.x = w16.x; v.y = w16.y; v.z = w16.z; v.w = w16.w;
             *(volatile lds_u32x4_t*)(rec + StageCfg::W16 + lane * 4u) = v;
@@ -207,7 +249,7 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
         wbase = wbase + 64u == StageCfg::WIN ? 0u : wbase + 64u;
     }
 #ifdef TSQ_STATS
-    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[0] = st_[0]; g_enc_stats[1] = TSQ_TOTAL(); g_enc_stats[32] = st_[20]; g_enc_stats[33] = st_[21]; g_enc_stats[34] = st_[20]; }
+    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[0] = st_[0]; g_enc_stats[1] = TSQ_TOTAL(); g_enc_stats[32] = st_[20]; g_enc_stats[33] = st_[21]; g_enc_stats[34] = st_[22]; }
 #endif
 }
 
