@@ -264,7 +264,7 @@ __device__ __forceinline__ void stream_emitter(const uint8_t* src, uint64_t avai
         asm volatile("" ::: "memory");
         const uint32_t have = uniform(__hip_atomic_load(&ctl[kCtlSyms], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         asm volatile("" ::: "memory");
-        if (have >= 64u * (batches + 1u) + (TSQ_X3 && end == 0u ? 64u : 0u)) {
+        if (have >= 64u * (batches + 1u)) {
             flush_batch(64u * batches, 64u);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the records are read: the ring entries may be reused
             batches++;

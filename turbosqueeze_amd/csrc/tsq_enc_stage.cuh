@@ -22,12 +22,6 @@
 // candidate, which is what the reference's table would hold (tsq_encode.cpp:76-79), or keeps the
 // gathered candidate when no twin was visited.
 #pragma once
-#ifndef TSQ_X2
-#define TSQ_X2 0
-#endif
-#ifndef TSQ_X3
-#define TSQ_X3 0
-#endif
 
 #include "tsq_common.cuh"
 #include "tsq_enc_util.cuh"
@@ -39,7 +33,7 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4_t lds_u32x4_t;
 
 struct StageCfg {
-    static constexpr uint32_t THREADS = 448;                      // seven wavefronts
+    static constexpr uint32_t THREADS = 512;                      // eight wavefronts
     static constexpr uint32_t EQ = 64, EV_WORDS = 4;              // events between WALK and ACCOUNT
     static constexpr uint32_t Q = 32;
     static constexpr uint32_t ITEM_WORDS = 80;
@@ -72,7 +66,7 @@ enum : uint32_t { kAH = 0, kATin = 1, kATp1 = 3, kATp2 = 5, kASpan = 7, kALane =
 // events between WALK and ACCOUNT, and their ctl words (10 events produced, 11 consumed, 12 queries answered, 13 the answer,
 // 14 the tile ACCOUNT works on: the tiles before it are accounted)
 enum : uint32_t { kEvSeg = 1, kEvHaz = 2, kEvEnd = 3 };
-enum : uint32_t { kCtlEvHead = 10, kCtlEvTail = 11, kCtlReplies = 12, kCtlReplyValue = 13, kCtlAccounted = 14 };
+enum : uint32_t { kCtlEvHead = 10, kCtlEvTail = 11, kCtlReplies = 12, kCtlReplyValue = 13, kCtlAccounted = 14, kCtlOrbitOdd = 15 };
 
 // Instrumented builds time only the spin loops (and only when they actually spin): s_memtime costs a few
 // hundred cycles, so finer timing distorts the pipeline it measures.  busy = total - waited.
@@ -267,13 +261,14 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
     uint64_t tw_m1 = 0, tw_m2 = 0, tw_m3 = 0;          // "has an earlier twin inside its tile" masks of those tiles
     uint32_t tin1_lo = 0, tin1_hi = 0, tin2_lo = 0, tin2_hi = 0, tin3_lo = 0, tin3_hi = 0;   // earlier-twin masks of the lanes of those tiles
     uint32_t wbase = 0;                                // (t * 64) % WIN
+    uint32_t scanned_seen = 0;
 #ifdef TSQ_STATS
     unsigned long long st_[32] = {0};
 #endif
     TSQ_BEGIN();
     for (uint32_t t = 0; t < n_tiles; ++t) {
         MREG_BEGIN(10);
-        if (!stage_wait(ctl, 2, t + 1u, 2)) break;
+        if (!stage_wait_seen(ctl, 2, t + 1u, scanned_seen, 2)) break;
         volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
         volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
         const uint32_t h = arr[kAH * 64];
@@ -412,7 +407,7 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
 
 // --------------------------------------------------------------------------------------------- ORBIT
 template <bool EXT>
-__device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t lane)
+__device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t lane, uint32_t parity)
 {
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
@@ -423,7 +418,9 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
     unsigned long long st_[32] = {0};
 #endif
     TSQ_BEGIN();
-    for (uint32_t t = 0; t < n_tiles; ++t) {
+    // two ORBIT wavefronts take the even and the odd tiles (nothing is carried from tile to tile)
+    uint32_t scanned_seen = 0, parsed_seen = 0;
+    for (uint32_t t = parity; t < n_tiles; t += 2u) {
         volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
         volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
         // ---- late classification of lanes whose only twins are in tile t-2.  By now the parser has (almost always)
@@ -434,13 +431,13 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
         uint32_t fix_sw = 0, fix_lw = 0;
         bool fix = false, clear_tp2 = false;
         if (t >= 2u) {
-            if (!stage_wait(ctl, 2, t + 1u, 6)) break;
+            if (!stage_wait_seen(ctl, 2, t + 1u, scanned_seen, 6)) break;
             const uint32_t tp2_lo = arr[kATp2 * 64], tp2_hi = arr[(kATp2 + 1) * 64];
             const uint32_t nearer = arr[kATin * 64] | arr[(kATin + 1) * 64] | arr[kATp1 * 64] | arr[(kATp1 + 1) * 64];
             const uint32_t p = (t << 6) + lane;
             const bool only2 = (tp2_lo | tp2_hi) != 0u && nearer == 0u && p < tail_from;
             if (__ballot(only2) != 0ull) {
-                if (!stage_wait(ctl, 5, t - 1u, 5)) break;                   // the parser has finished tile t-2
+                if (!stage_wait_seen(ctl, 5, t - 1u, parsed_seen, 5)) break;                   // the parser has finished tile t-2
                 const uint32_t slot = 16u + 2u * ((t - 2u) & 7u);
                 const uint32_t v2_lo = uniform(__hip_atomic_load(&ctl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 const uint32_t v2_hi = uniform(__hip_atomic_load(&ctl[slot + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -488,10 +485,10 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
         arr[kANx * 64] = nx;
         arr[kAOrb * 64] = (uint32_t)orb;
         arr[(kAOrb + 1) * 64] = (uint32_t)(orb >> 32);
-        stage_publish(ctl, 4, t + 1u, lane);
+        stage_publish(ctl, parity ? kCtlOrbitOdd : 4u, t + 1u, lane);
     }
 #ifdef TSQ_STATS
-    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[6] = st_[6] + st_[5]; g_enc_stats[7] = TSQ_TOTAL(); }
+    if (blockIdx.x == 0 && lane == 0 && parity == 0u) { g_enc_stats[6] = st_[6] + st_[5]; g_enc_stats[7] = TSQ_TOTAL(); }
 #endif
 }
 
@@ -587,11 +584,12 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
         uint64_t vall = 0;
         if (v < base + 64u) {
             // (the serial stage polls without sleeping: a wake-up from s_sleep costs it up to 64 cycles per hand-off)
-            if (!stage_ready(ctl, 4, t + 1u)) {
+            const uint32_t orbit_word = (t & 1u) ? kCtlOrbitOdd : 4u;
+            if (!stage_ready(ctl, orbit_word, t + 1u)) {
 #ifdef TSQ_STATS
                 const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
 #endif
-                while (!stage_ready(ctl, 4, t + 1u)) {}
+                while (!stage_ready(ctl, orbit_word, t + 1u)) {}
 #ifdef TSQ_STATS
                 st_[8] += __builtin_amdgcn_s_memtime() - w0_;
 #endif
@@ -1055,9 +1053,9 @@ __global__ __launch_bounds__(StageCfg::THREADS) void enc_stage_kernel(const uint
     // symbols; ORBIT (which waits a third of its time) shares with the builder, MATCH with ACCOUNT.
     if (role == 0) stage_walk<EXT, WINDOW>(src, avail, n, lds3, lane);
     else if (role == 6) stage_account(n, lds3, lane);
-    else if (role == (TSQ_X2 ? 1 : 3)) stage_scan<WINDOW>(src, avail, n, lds3, lane);
+    else if (role == 3) stage_scan<WINDOW>(src, avail, n, lds3, lane);
     else if (role == 2) stage_match<EXT, WINDOW>(src, avail, n, table, lds3, lane);
-    else if (role == (TSQ_X2 ? 3 : 1)) stage_orbit<EXT>(n, lds3, lane);
+    else if (role == 1 || role == 7) stage_orbit<EXT>(n, lds3, lane, role == 7 ? 1u : 0u);
     else if (role == 4) stream_emitter<StageCfg>(src, avail, out, lds3, lane, b, sizes, status);
     else stream_builder<StageCfg>(lds3, lane);
 }
