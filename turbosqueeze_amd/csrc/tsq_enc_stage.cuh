@@ -33,25 +33,23 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4_t lds_u32x4_t;
 
 struct StageCfg {
-    static constexpr uint32_t THREADS = 512;                      // eight wavefronts
+    static constexpr uint32_t THREADS = 576;                      // nine wavefronts
     static constexpr uint32_t EQ = 64, EV_WORDS = 4;              // events between WALK and ACCOUNT
-    static constexpr uint32_t Q = 32;
+    static constexpr uint32_t Q = 16;                             // items between ACCOUNT and BUILDER
     static constexpr uint32_t ITEM_WORDS = 80;
     static constexpr uint32_t RING = 256;                          // symbol records between BUILDER and EMIT (four batches)
     static constexpr uint32_t R = 8;                              // tile records in flight
     static constexpr uint32_t OWN_MASK = 0x7FFFu;                 // owner image: hash folded to 15 bits
     static constexpr uint32_t WIN = 73728;                        // input window ring: the last 64 KiB of input and then some (a multiple of 64)
-    static constexpr uint32_t F_MASK = 0xFFFu;                    // MATCH's filter of tile t-3's visited lanes: hash folded to 12 bits
     static constexpr uint32_t W16 = 16;                           // word offset of the uint4-per-lane input words
     static constexpr uint32_t ARR = 16 + 256;                     // word offset of the u32-per-lane arrays
-    static constexpr uint32_t REC_WORDS = ARR + 12 * 64;
+    static constexpr uint32_t REC_WORDS = ARR + 14 * 64;
     static constexpr uint32_t off_owner = 0;                                   // u8[65536]
     static constexpr uint32_t off_queue = OWN_MASK + 1u;                       // u32[Q * ITEM_WORDS]
     static constexpr uint32_t off_ring = off_queue + Q * ITEM_WORDS * 4;       // u32[RING]
     static constexpr uint32_t off_rec = off_ring + RING * 4;                   // u32[R * REC_WORDS]
     static constexpr uint32_t off_ctl = off_rec + R * REC_WORDS * 4;           // u32[64]
-    static constexpr uint32_t off_f = off_ctl + 256;                           // u8[F_MASK + 1]
-    static constexpr uint32_t off_evq = off_f + F_MASK + 1u;                   // u32[EQ * EV_WORDS]
+    static constexpr uint32_t off_evq = off_ctl + 256;                         // u32[EQ * EV_WORDS]
     static constexpr uint32_t off_win = off_evq + EQ * EV_WORDS * 4;           // u8[WIN + 32]: the ring, its first 32 bytes mirrored at the end
     static constexpr uint32_t total = off_win + WIN + 32;
     static constexpr uint32_t total_lean = off_win;                            // without the window: two blocks fit one CU
@@ -62,11 +60,11 @@ struct StageCfg {
 //         per-lane arrays: 0 hash  1,2 twins in this tile (earlier lanes)  3,4 twins in tile t-1  5,6 twins in tile t-2
 //                          7 spanword  8 candidate | nibble << 24  9 orbit halt  10,11 orbit mask
 // spanword: natural span (bits 0..7) | hard (8) | has a twin (9) | certain match (10) | near twin (11) | common prefix (16..23)
-enum : uint32_t { kAH = 0, kATin = 1, kATp1 = 3, kATp2 = 5, kASpan = 7, kALane = 8, kANx = 9, kAOrb = 10 };
+enum : uint32_t { kAH = 0, kATin = 1, kATp1 = 3, kATp2 = 5, kASpan = 7, kALane = 8, kANx = 9, kAOrb = 10, kATp3 = 12 };
 // events between WALK and ACCOUNT, and their ctl words (10 events produced, 11 consumed, 12 queries answered, 13 the answer,
 // 14 the tile ACCOUNT works on: the tiles before it are accounted)
 enum : uint32_t { kEvSeg = 1, kEvHaz = 2, kEvEnd = 3 };
-enum : uint32_t { kCtlEvHead = 10, kCtlEvTail = 11, kCtlReplies = 12, kCtlReplyValue = 13, kCtlAccounted = 14, kCtlOrbitOdd = 15 };
+enum : uint32_t { kCtlEvHead = 10, kCtlEvTail = 11, kCtlReplies = 12, kCtlReplyValue = 13, kCtlAccounted = 14, kCtlOrbitOdd = 15, kCtlCommitted = 33 };
 
 // Instrumented builds time only the spin loops (and only when they actually spin): s_memtime costs a few
 // hundred cycles, so finer timing distorts the pipeline it measures.  busy = total - waited.
@@ -151,7 +149,7 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
     uint32_t h_m1 = 0xFFFFFFFFu, h_m2 = 0xFFFFFFFFu, h_m3 = 0xFFFFFFFFu;   // hashes of tiles t-1 .. t-3 (per lane)
     uint32_t id = 1;                                    // (t % 3) + 1: which of the three live tiles an owner tag names
     uint32_t wbase = 0;                                 // (t * 64) % WIN
-    uint32_t parsed_seen = 0, accounted_seen = 0;
+    uint32_t parsed_seen = 0, accounted_seen = 0, posted_seen = 0;
 #ifdef TSQ_STATS
     unsigned long long st_[32] = {0};
 #endif
@@ -161,6 +159,7 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
         // the slot of tile t-R is free once WALK has finished tile t-R+2 (it reads the words of two tiles back) and ACCOUNT is past tile t-R
         if (t + 3u > StageCfg::R && !stage_wait_seen(ctl, 5, t + 3u - StageCfg::R, parsed_seen, 0)) break;
         if (t + 1u > StageCfg::R && !stage_wait_seen(ctl, kCtlAccounted, t + 1u - StageCfg::R, accounted_seen, 0)) break;
+        if (t + 1u > StageCfg::R && !stage_wait_seen(ctl, kCtlCommitted, t + 1u - StageCfg::R, posted_seen, 0)) break;
         const uint32_t p = (t << 6) + lane;
         const uint4 w16 = w_next;
         w_next = ld128z(src, (uint64_t)p + 64u, avail);    // the next tile's words: this wave's only global access, a full iteration ahead
@@ -171,30 +170,35 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
         volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
         volatile lds_u32_t* rec_m1 = recs + ((t + StageCfg::R - 1u) % StageCfg::R) * StageCfg::REC_WORDS;
         volatile lds_u32_t* rec_m2 = recs + ((t + StageCfg::R - 2u) % StageCfg::R) * StageCfg::REC_WORDS;
-        // retire the entries of tile t-3 (same id as tile t) unless a later tile has taken the bucket over
+        volatile lds_u32_t* rec_m3 = recs + ((t + StageCfg::R - 3u) % StageCfg::R) * StageCfg::REC_WORDS;
+        // The bucket's owner: the most recent lane of tiles t-1 .. t-3 with this folded hash (tile t-3 has tile t's id; nothing of
+        // tile t is in the image yet).  Then the entries of tile t-3 retire, unless a later tile has taken the bucket over.
+        const uint32_t before = owner[hf];
         if (t >= 3u && ((uint32_t)owner[h_m3 & StageCfg::OWN_MASK] >> 6) == id) owner[h_m3 & StageCfg::OWN_MASK] = 0;
-        const uint32_t before = owner[hf];              // non-zero: the most recent lane of tile t-1 or t-2 with this folded hash
         owner[hf] = (uint8_t)tag;
         const uint32_t after = owner[hf];
-        // ---- twins in the two previous tiles (tile t-3 and older are MATCH's business: by then the parser has decided them).
-        // The owner of the bucket, lane q of tile t-1 or t-2, is the MOST RECENT position with this folded hash.  If its hash is
-        // this lane's hash, this lane's twins are q and q's own twins (already exact, by induction): no search.  If it is another
-        // hash (a fold collision: 128 live entries in 32 K buckets), a twin may hide behind it: settled with ballots below.
-        uint64_t twin_p1 = 0, twin_p2 = 0;
+        // ---- twins in the three previous tiles (t-1, t-2: the parser's business; t-3: MATCH folds its visited lanes into the
+        // candidates; older tiles are in the table).  If the owner's hash is this lane's hash, this lane's twins are the owner and
+        // the owner's own twins (already exact, by induction): no search.  If it is another hash (a fold collision: 192 live
+        // entries in 32 K buckets), a twin may hide behind it: settled with ballots below.
+        uint64_t twin_p1 = 0, twin_p2 = 0, twin_p3 = 0;
         bool unsure = false;
         if (__ballot(before != 0u) != 0ull) {
             const uint32_t q = before & 63u;
-            const bool in_p1 = (before >> 6) == id_m1;
-            volatile lds_u32_t* qa = (in_p1 ? rec_m1 : rec_m2) + StageCfg::ARR + q;
+            const uint32_t bid = before >> 6;
+            const bool in_p1 = bid == id_m1, in_p3 = bid == id;
+            volatile lds_u32_t* qa = (in_p1 ? rec_m1 : in_p3 ? rec_m3 : rec_m2) + StageCfg::ARR + q;
             const uint32_t hq = qa[kAH * 64];
-            const uint32_t qin_lo = qa[kATin * 64], qin_hi = qa[(kATin + 1) * 64];
-            const uint32_t qp1_lo = qa[kATp1 * 64], qp1_hi = qa[(kATp1 + 1) * 64];
+            const uint64_t q_in = (uint64_t)qa[kATin * 64] | ((uint64_t)qa[(kATin + 1) * 64] << 32);
+            const uint64_t q_p1 = (uint64_t)qa[kATp1 * 64] | ((uint64_t)qa[(kATp1 + 1) * 64] << 32);
+            const uint64_t q_p2 = (uint64_t)qa[kATp2 * 64] | ((uint64_t)qa[(kATp2 + 1) * 64] << 32);
             const bool same = before != 0u && hq == h;
             unsure = before != 0u && hq != h;
-            const uint64_t chain = ((uint64_t)qin_lo | ((uint64_t)qin_hi << 32)) | (1ull << q);
+            const uint64_t chain = q_in | (1ull << q);
             if (same) {
                 twin_p1 = in_p1 ? chain : 0ull;
-                twin_p2 = in_p1 ? ((uint64_t)qp1_lo | ((uint64_t)qp1_hi << 32)) : chain;
+                twin_p2 = in_p1 ? q_p1 : in_p3 ? 0ull : chain;
+                twin_p3 = in_p1 ? q_p2 : in_p3 ? chain : q_p1;
             }
         }
         // twins inside the tile: for each lane the mask of EARLIER lanes with the same hash
@@ -216,9 +220,9 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
             while (maybe) {
                 TSQ_CNT(21, 1);
                 const uint32_t hl = rdlane(h, lsb64(maybe));
-                const uint64_t g1 = __ballot(h_m1 == hl), g2 = __ballot(h_m2 == hl);
+                const uint64_t g1 = __ballot(h_m1 == hl), g2 = __ballot(h_m2 == hl), g3 = __ballot(h_m3 == hl);
                 const uint64_t grp_cur = __ballot(h == hl);
-                if (h == hl) { twin_p1 = g1; twin_p2 = g2; }
+                if (h == hl) { twin_p1 = g1; twin_p2 = g2; twin_p3 = g3; }
                 maybe &= ~grp_cur;
             }
         }
@@ -237,6 +241,7 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
         arr[kATin * 64] = (uint32_t)twin_in;  arr[(kATin + 1) * 64] = (uint32_t)(twin_in >> 32);
         arr[kATp1 * 64] = (uint32_t)twin_p1;  arr[(kATp1 + 1) * 64] = (uint32_t)(twin_p1 >> 32);
         arr[kATp2 * 64] = (uint32_t)twin_p2;  arr[(kATp2 + 1) * 64] = (uint32_t)(twin_p2 >> 32);
+        arr[kATp3 * 64] = (uint32_t)twin_p3;  arr[(kATp3 + 1) * 64] = (uint32_t)(twin_p3 >> 32);
         stage_publish(ctl, 2, t + 1u, lane);
         h_m3 = h_m2; h_m2 = h_m1; h_m1 = h;
         id = id == 3u ? 1u : id + 1u;
@@ -253,15 +258,12 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
 {
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
-    volatile lds_u8_t* filt = lds + StageCfg::off_f;
     constexpr uint32_t kDMin = EXT ? 128u : 64u;
     const uint32_t tail_from = n >= 5u ? n - 5u : 0u;
     const uint32_t n_tiles = (n >> 6) + 3u;
     uint32_t h_m1 = 0, h_m2 = 0, h_m3 = 0;
-    uint64_t tw_m1 = 0, tw_m2 = 0, tw_m3 = 0;          // "has an earlier twin inside its tile" masks of those tiles
-    uint32_t tin1_lo = 0, tin1_hi = 0, tin2_lo = 0, tin2_hi = 0, tin3_lo = 0, tin3_hi = 0;   // earlier-twin masks of the lanes of those tiles
     uint32_t wbase = 0;                                // (t * 64) % WIN
-    uint32_t scanned_seen = 0;
+    uint32_t scanned_seen = 0, committed_seen = 0;
 #ifdef TSQ_STATS
     unsigned long long st_[32] = {0};
 #endif
@@ -277,50 +279,27 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         const uint64_t twin_in = (uint64_t)arr[kATin * 64] | ((uint64_t)arr[(kATin + 1) * 64] << 32);
         const uint64_t twin_p1 = (uint64_t)arr[kATp1 * 64] | ((uint64_t)arr[(kATp1 + 1) * 64] << 32);
         const uint32_t tp2_any = arr[kATp2 * 64] | arr[(kATp2 + 1) * 64];
-        const uint64_t twins_here = (uint64_t)uniform(rec[0]) | ((uint64_t)uniform(rec[1]) << 32);
+        const uint32_t tp3_lo = arr[kATp3 * 64], tp3_hi = arr[(kATp3 + 1) * 64];
         MREG_END(10);
         MREG_BEGIN(12);
-        // ---- the table holds the visits of tiles <= t-4 (commit(t-4) was issued at the end of the previous iteration):
-        //      gather from it right away, without waiting for the parser ...
-        const uint32_t tv_old = table[h];
+        // ---- the table holds the visits of tiles <= t-4 (the COMMIT wave has published them: its stores are complete and the
+        //      wavefronts of a workgroup share the vector L1): gather from it right away, without waiting for the parser ...
+        if (t >= 4u && !stage_wait_seen(ctl, kCtlCommitted, t - 3u, committed_seen, 3)) break;
+        const uint32_t tv_old = table[h];                // (a plain load: an atomic one is waited for on the spot, and the gather's latency must stay hidden)
         MREG_END(12);
         MREG_BEGIN(11);
         // ... and bring the entries up to "visits of tiles <= t-3" once the parser has finished tile t-3: a lane with a
-        // visited twin there takes the most recent one (what the committed table would hold), the others keep theirs.
-        // The visited lanes of tile t-3 post themselves in a small filter (hash folded to 12 bits, the highest lane of a
-        // hash last, like the commit); a lane of tile t that finds its own hash there has found its most recent visited
-        // twin; one that finds another hash (a fold collision, rare) is settled with ballots.
+        // visited twin there (SCAN's exact mask) takes the most recent one -- what the committed table would hold --, the others
+        // keep theirs.
         uint32_t tv = tv_old;
         if (t >= 3u) {
             if (!stage_wait(ctl, 5, t - 2u, 3)) break;
             const uint32_t slot = 16u + 2u * ((t - 3u) & 7u);
-            const uint64_t vis = (uint64_t)uniform(__hip_atomic_load(&ctl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) |
-                                 ((uint64_t)uniform(__hip_atomic_load(&ctl[slot + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) << 32);
-            const uint32_t p3 = ((t - 3u) << 6) + lane;
-            const bool mine = (vis >> lane) & 1ull;
-            const uint32_t f3 = h_m3 & StageCfg::F_MASK;
-            // among equal hashes the highest visited lane must win: lanes with an earlier twin store afterwards ...
-            if (((vis & ~tw_m3) >> lane) & 1ull) { table[h_m3] = (uint16_t)p3; filt[f3] = (uint8_t)(0x80u | lane); }
-            // ... one store per hash group: the highest visited lane of a group stores, its earlier twins are dropped unseen
-            // (a block of equal bytes is ONE group of 64 lanes)
-            uint64_t late = vis & tw_m3;
-            while (late) {
-                const uint32_t top = msb64(late);
-                if (lane == top) { table[h_m3] = (uint16_t)p3; filt[f3] = (uint8_t)(0x80u | lane); }
-                late &= ~((uint64_t)rdlane(tin3_lo, top) | ((uint64_t)rdlane(tin3_hi, top) << 32) | (1ull << top));
-            }
-            const uint32_t seen = filt[h & StageCfg::F_MASK];
-            const uint32_t q = seen & 63u;
-            const uint32_t hq = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(q << 2), (int)h_m3);
-            if (seen != 0u && hq == h) tv = (((t - 3u) << 6) + q) & 0xFFFFu;
-            uint64_t unsure = __ballot(seen != 0u && hq != h);
-            while (unsure) {                                  // another hash owns the filter slot: this hash's twins, exactly
-                const uint32_t hl = rdlane(h, lsb64(unsure));
-                const uint64_t g3 = __ballot(h_m3 == hl) & vis;
-                if (h == hl && g3 != 0ull) tv = (((t - 3u) << 6) + msb64(g3)) & 0xFFFFu;
-                unsure &= ~__ballot(h == hl);
-            }
-            if (mine) filt[f3] = 0;                           // the filter only ever holds one tile
+            const uint32_t vis_lo = uniform(__hip_atomic_load(&ctl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            const uint32_t vis_hi = uniform(__hip_atomic_load(&ctl[slot + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            const uint32_t hit_lo = tp3_lo & vis_lo, hit_hi = tp3_hi & vis_hi;
+            const uint32_t q = hit_hi ? 63u - (uint32_t)__builtin_clz(hit_hi) : 31u - (uint32_t)__builtin_clz(hit_lo | 1u);
+            if ((hit_lo | hit_hi) != 0u) tv = (((t - 3u) << 6) + q) & 0xFFFFu;
         }
         MREG_END(11);
         // ---- candidates of tile t
@@ -396,12 +375,52 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         stage_publish(ctl, 3, t + 1u, lane);
         MREG_END(14);
         h_m3 = h_m2; h_m2 = h_m1; h_m1 = h;
-        tw_m3 = tw_m2; tw_m2 = tw_m1; tw_m1 = twins_here;
-        tin3_lo = tin2_lo; tin3_hi = tin2_hi; tin2_lo = tin1_lo; tin2_hi = tin1_hi; tin1_lo = (uint32_t)twin_in; tin1_hi = (uint32_t)(twin_in >> 32);
         wbase = wbase + 64u == StageCfg::WIN ? 0u : wbase + 64u;
     }
 #ifdef TSQ_STATS
     if (blockIdx.x == 0 && lane == 0) { g_enc_stats[2] = st_[2]; g_enc_stats[3] = st_[3]; g_enc_stats[4] = TSQ_TOTAL(); g_enc_stats[13] = st_[13]; g_enc_stats[14] = st_[14]; g_enc_stats[35] = st_[20]; g_enc_stats[36] = st_[21]; }
+#endif
+}
+
+// -------------------------------------------------------------------------------------------- COMMIT
+// The position table's writer.  Tile by tile, as soon as WALK has published a tile's visited lanes: their positions go to the
+// table (tsq_encode.cpp:79; among equal hashes the highest visited lane last) and into MATCH's filter for that tile (two filters,
+// used in turn).  `posted` tells MATCH the filter is ready; `committed` -- after the stores have completed -- that the table is.
+__device__ __forceinline__ void stage_commit(uint32_t n, uint16_t* table, lds_u8_t* lds, uint32_t lane)
+{
+    volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
+    lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
+    const uint32_t n_tiles = (n >> 6) + 3u;
+#ifdef TSQ_STATS
+    unsigned long long st_[32] = {0};
+#endif
+    TSQ_BEGIN();
+    for (uint32_t t = 0; t < n_tiles; ++t) {
+        if (!stage_wait(ctl, 5, t + 1u, 3)) break;
+        volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
+        volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
+        const uint32_t h = arr[kAH * 64];
+        const uint32_t tin_lo = arr[kATin * 64], tin_hi = arr[(kATin + 1) * 64];
+        const uint64_t tw = (uint64_t)uniform(rec[0]) | ((uint64_t)uniform(rec[1]) << 32);   // lanes with an earlier twin inside the tile
+        const uint32_t slot = 16u + 2u * (t & 7u);
+        const uint64_t vis = (uint64_t)uniform(__hip_atomic_load(&ctl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) |
+                             ((uint64_t)uniform(__hip_atomic_load(&ctl[slot + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) << 32);
+        const uint32_t p = (t << 6) + lane;
+        // among equal hashes the highest visited lane must win: lanes with an earlier twin store afterwards ...
+        if (((vis & ~tw) >> lane) & 1ull) table[h] = (uint16_t)p;
+        // ... one store per hash group: the highest visited lane of a group stores, its earlier twins are dropped unseen
+        // (a block of equal bytes is ONE group of 64 lanes)
+        uint64_t late = vis & tw;
+        while (late) {
+            const uint32_t top = msb64(late);
+            if (lane == top) table[h] = (uint16_t)p;
+            late &= ~((uint64_t)rdlane(tin_lo, top) | ((uint64_t)rdlane(tin_hi, top) << 32) | (1ull << top));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the table stores are complete
+        stage_publish(ctl, kCtlCommitted, t + 1u, lane);
+    }
+#ifdef TSQ_STATS
+    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[45] = st_[3] + st_[4]; g_enc_stats[46] = TSQ_TOTAL(); }
 #endif
 }
 
@@ -464,7 +483,7 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
         if (!stage_wait(ctl, 3, t + 1u, 6)) break;
         uint32_t sw = arr[kASpan * 64];
         if (fix) { sw = fix_sw; arr[kASpan * 64] = fix_sw; arr[kALane * 64] = fix_lw; }
-        if (clear_tp2) { arr[kATp2 * 64] = 0; arr[(kATp2 + 1) * 64] = 0; }
+        if (clear_tp2) { sw |= 0x1000u; arr[kASpan * 64] = sw; }      // (SCAN's masks stay as they are: later tiles inherit from them)
         // the whole orbit of every lane, by pointer doubling: `nx` = where the orbit started at this lane halts
         // (lane, or position past the tile: 7 bits | halted: bit 7), `orb` = the lanes it visits before that.
         // A hop halts when it lands on a hard lane or past the tile.  Twin lanes do not halt: the parser takes
@@ -602,7 +621,8 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
             const uint32_t orb_lo = arr[kAOrb * 64], orb_hi = arr[(kAOrb + 1) * 64];
             const uint32_t tin_lo = arr[kATin * 64], tin_hi = arr[(kATin + 1) * 64];
             const uint32_t tp1_lo = arr[kATp1 * 64], tp1_hi = arr[(kATp1 + 1) * 64];
-            const uint32_t tp2_lo = arr[kATp2 * 64], tp2_hi = arr[(kATp2 + 1) * 64];
+            const uint32_t settled = (spanword & 0x1000u) ? 0u : 0xFFFFFFFFu;     // ORBIT has settled the lane's twins in tile t-2
+            const uint32_t tp2_lo = arr[kATp2 * 64] & settled, tp2_hi = arr[(kATp2 + 1) * 64] & settled;
             const uint64_t hard = __ballot((spanword & 0x100u) != 0u);
             const uint64_t near_m = __ballot((spanword & 0x800u) != 0u);
             const uint64_t certain_m = __ballot((spanword & 0x400u) != 0u);
@@ -1043,8 +1063,6 @@ __global__ __launch_bounds__(StageCfg::THREADS) void enc_stage_kernel(const uint
         if (threadIdx.x < 64) reinterpret_cast<uint32_t*>(stage_lds + StageCfg::off_ctl)[threadIdx.x] = 0;
         uint4* o4 = reinterpret_cast<uint4*>(stage_lds + StageCfg::off_owner);          // owner image: no valid entries
         for (uint32_t k = threadIdx.x; k < (StageCfg::OWN_MASK + 1u) / 16; k += StageCfg::THREADS) o4[k] = make_uint4(0, 0, 0, 0);
-        uint4* f4 = reinterpret_cast<uint4*>(stage_lds + StageCfg::off_f);              // MATCH's filter: empty
-        for (uint32_t k = threadIdx.x; k < (StageCfg::F_MASK + 1u) / 16; k += StageCfg::THREADS) f4[k] = make_uint4(0, 0, 0, 0);
         if (threadIdx.x == 0) { out[0] = (uint8_t)n; out[1] = (uint8_t)(n >> 8); out[2] = (uint8_t)(n >> 16); }
     }
     __syncthreads();
@@ -1053,6 +1071,7 @@ __global__ __launch_bounds__(StageCfg::THREADS) void enc_stage_kernel(const uint
     // symbols; ORBIT (which waits a third of its time) shares with the builder, MATCH with ACCOUNT.
     if (role == 0) stage_walk<EXT, WINDOW>(src, avail, n, lds3, lane);
     else if (role == 6) stage_account(n, lds3, lane);
+    else if (role == 8) stage_commit(n, table, lds3, lane);
     else if (role == 3) stage_scan<WINDOW>(src, avail, n, lds3, lane);
     else if (role == 2) stage_match<EXT, WINDOW>(src, avail, n, table, lds3, lane);
     else if (role == 1 || role == 7) stage_orbit<EXT>(n, lds3, lane, role == 7 ? 1u : 0u);
