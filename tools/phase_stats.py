@@ -29,13 +29,14 @@ codec.set_variant(int(os.environ.get("ENC_VARIANT", "0")), int(os.environ.get("D
 blob = codec.compress(src, ext)
 back = codec.decompress(blob)
 assert torch.equal(back, src)
-enc = (C.c_ulonglong * 48)()
+enc = (C.c_ulonglong * 64)()
 dec = (C.c_ulonglong * 16)()
 L.tsqa_debug_stats(enc, dec)
 e = list(enc); d = list(dec)
 T = max(e[15], 1)
 print(f"ENC staged pipeline block0 (tiles parsed={e[15]}, symbols={e[16]}); cycles per tile, busy = total - waited:")
-print("  SCAN    total=%.0f waited(ring)=%.0f busy=%.0f" % (e[1] / T, e[0] / T, (e[1] - e[0]) / T))
+print("  HASH    total=%.0f waited(ring)=%.0f busy=%.0f" % (e[1] / T, e[0] / T, (e[1] - e[0]) / T))
+print("  TWINS   total=%.0f waited(hash)=%.0f busy=%.0f" % (e[49] / T, e[48] / T, (e[49] - e[48]) / T))
 print("          unsure lanes per tile=%.2f, settle rounds per tile=%.2f, in-tile group rounds per tile=%.2f" % (e[32] / T, e[33] / T, e[34] / T))
 print("  MATCH   total=%.0f waited(scan)=%.0f waited(parser)=%.0f busy=%.0f" % (e[4] / T, e[2] / T, e[3] / T, (e[4] - e[2] - e[3]) / T))
 print("          length-extension rounds per tile=%.2f (from the window ring %.2f)" % (e[36] / T, e[35] / T))

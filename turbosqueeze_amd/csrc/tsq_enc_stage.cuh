@@ -33,7 +33,7 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4_t lds_u32x4_t;
 
 struct StageCfg {
-    static constexpr uint32_t THREADS = 576;                      // nine wavefronts
+    static constexpr uint32_t THREADS = 640;                      // ten wavefronts
     static constexpr uint32_t EQ = 64, EV_WORDS = 4;              // events between WALK and ACCOUNT
     static constexpr uint32_t Q = 16;                             // items between ACCOUNT and BUILDER
     static constexpr uint32_t ITEM_WORDS = 80;
@@ -43,7 +43,7 @@ struct StageCfg {
     static constexpr uint32_t WIN = 73728;                        // input window ring: the last 64 KiB of input and then some (a multiple of 64)
     static constexpr uint32_t W16 = 16;                           // word offset of the uint4-per-lane input words
     static constexpr uint32_t ARR = 16 + 256;                     // word offset of the u32-per-lane arrays
-    static constexpr uint32_t REC_WORDS = ARR + 14 * 64;
+    static constexpr uint32_t REC_WORDS = ARR + 15 * 64;
     static constexpr uint32_t off_owner = 0;                                   // u8[65536]
     static constexpr uint32_t off_queue = OWN_MASK + 1u;                       // u32[Q * ITEM_WORDS]
     static constexpr uint32_t off_ring = off_queue + Q * ITEM_WORDS * 4;       // u32[RING]
@@ -60,11 +60,11 @@ struct StageCfg {
 //         per-lane arrays: 0 hash  1,2 twins in this tile (earlier lanes)  3,4 twins in tile t-1  5,6 twins in tile t-2
 //                          7 spanword  8 candidate | nibble << 24  9 orbit halt  10,11 orbit mask
 // spanword: natural span (bits 0..7) | hard (8) | has a twin (9) | certain match (10) | near twin (11) | common prefix (16..23)
-enum : uint32_t { kAH = 0, kATin = 1, kATp1 = 3, kATp2 = 5, kASpan = 7, kALane = 8, kANx = 9, kAOrb = 10, kATp3 = 12 };
+enum : uint32_t { kAH = 0, kATin = 1, kATp1 = 3, kATp2 = 5, kASpan = 7, kALane = 8, kANx = 9, kAOrb = 10, kATp3 = 12, kAOwn = 14 };
 // events between WALK and ACCOUNT, and their ctl words (10 events produced, 11 consumed, 12 queries answered, 13 the answer,
 // 14 the tile ACCOUNT works on: the tiles before it are accounted)
 enum : uint32_t { kEvSeg = 1, kEvHaz = 2, kEvEnd = 3 };
-enum : uint32_t { kCtlEvHead = 10, kCtlEvTail = 11, kCtlReplies = 12, kCtlReplyValue = 13, kCtlAccounted = 14, kCtlOrbitOdd = 15, kCtlCommitted = 33 };
+enum : uint32_t { kCtlEvHead = 10, kCtlEvTail = 11, kCtlReplies = 12, kCtlReplyValue = 13, kCtlAccounted = 14, kCtlOrbitOdd = 15, kCtlCommitted = 33, kCtlHashed = 34 };
 
 // Instrumented builds time only the spin loops (and only when they actually spin): s_memtime costs a few
 // hundred cycles, so finer timing distorts the pipeline it measures.  busy = total - waited.
@@ -139,44 +139,88 @@ __device__ __forceinline__ void stage_publish(lds_u32_t* ctl, uint32_t word, uin
 }
 
 // ---------------------------------------------------------------------------------------------- SCAN
+// SCAN is two wavefronts: HASH loads the tile's input words, hashes them and runs the owner image (which lanes share a
+// bucket: a filter); TWINS turns that into the exact twin masks.
 template <bool WINDOW>
-__device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, uint32_t n, lds_u8_t* lds, uint32_t lane)
+__device__ __forceinline__ void stage_hash(const uint8_t* src, uint64_t avail, uint32_t n, lds_u8_t* lds, uint32_t lane)
 {
     volatile lds_u8_t* owner = lds + StageCfg::off_owner;
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
     const uint32_t n_tiles = (n >> 6) + 3u;            // visits reach at most n + 63
-    uint32_t h_m1 = 0xFFFFFFFFu, h_m2 = 0xFFFFFFFFu, h_m3 = 0xFFFFFFFFu;   // hashes of tiles t-1 .. t-3 (per lane)
+    uint32_t hf_m1 = 0, hf_m2 = 0, hf_m3 = 0;           // folded hashes of tiles t-1 .. t-3 (per lane)
     uint32_t id = 1;                                    // (t % 3) + 1: which of the three live tiles an owner tag names
     uint32_t wbase = 0;                                 // (t * 64) % WIN
-    uint32_t parsed_seen = 0, accounted_seen = 0, posted_seen = 0;
+    uint32_t parsed_seen = 0, accounted_seen = 0, committed_seen = 0;
 #ifdef TSQ_STATS
     unsigned long long st_[32] = {0};
 #endif
     TSQ_BEGIN();
     uint4 w_next = ld128z(src, lane, avail);
     for (uint32_t t = 0; t < n_tiles; ++t) {
-        // the slot of tile t-R is free once WALK has finished tile t-R+2 (it reads the words of two tiles back) and ACCOUNT is past tile t-R
+        // the slot of tile t-R is free once WALK has finished tile t-R+2 (it reads the words of two tiles back) and ACCOUNT and
+        // COMMIT are past tile t-R
         if (t + 3u > StageCfg::R && !stage_wait_seen(ctl, 5, t + 3u - StageCfg::R, parsed_seen, 0)) break;
         if (t + 1u > StageCfg::R && !stage_wait_seen(ctl, kCtlAccounted, t + 1u - StageCfg::R, accounted_seen, 0)) break;
-        if (t + 1u > StageCfg::R && !stage_wait_seen(ctl, kCtlCommitted, t + 1u - StageCfg::R, posted_seen, 0)) break;
+        if (t + 1u > StageCfg::R && !stage_wait_seen(ctl, kCtlCommitted, t + 1u - StageCfg::R, committed_seen, 0)) break;
         const uint32_t p = (t << 6) + lane;
         const uint4 w16 = w_next;
         w_next = ld128z(src, (uint64_t)p + 64u, avail);    // the next tile's words: this wave's only global access, a full iteration ahead
         const uint32_t h = hash4(w16.x);
         const uint32_t hf = h & StageCfg::OWN_MASK;
         const uint32_t tag = (id << 6) | lane;          // never 0: the image starts zeroed
-        const uint32_t id_m1 = id == 1u ? 3u : id - 1u; // the id of tile t-1 (the third one is tile t-2's)
+        volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
+        // The bucket's owner: the most recent lane of tiles t-1 .. t-3 with this folded hash (tile t-3 has tile t's id; nothing of
+        // tile t is in the image yet).  Then the entries of tile t-3 retire, unless a later tile has taken the bucket over.
+        const uint32_t before = owner[hf];
+        if (t >= 3u && ((uint32_t)owner[hf_m3] >> 6) == id) owner[hf_m3] = 0;
+        owner[hf] = (uint8_t)tag;
+        const uint32_t after = owner[hf];
+        {
+            u32x4_t v; v.x = w16.x; v.y = w16.y; v.z = w16.z; v.w = w16.w;
+            *(volatile lds_u32x4_t*)(rec + StageCfg::W16 + lane * 4u) = v;
+            // the tile's 64 input bytes join the window ring MATCH takes candidate bytes from
+            if (WINDOW && (lane & 15u) == 0u) {
+                *(volatile lds_u32x4_t*)(lds + StageCfg::off_win + wbase + lane) = v;
+                if (wbase == 0u && lane < 32u) *(volatile lds_u32x4_t*)(lds + StageCfg::off_win + StageCfg::WIN + lane) = v;
+            }
+        }
+        volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
+        arr[kAH * 64] = h;
+        arr[kAOwn * 64] = before | (id << 8) | (after != tag ? 0x1000u : 0u);     // owner before | this tile's id | another lane of the tile took the bucket
+        stage_publish(ctl, kCtlHashed, t + 1u, lane);
+        hf_m3 = hf_m2; hf_m2 = hf_m1; hf_m1 = hf;
+        id = id == 3u ? 1u : id + 1u;
+        wbase = wbase + 64u == StageCfg::WIN ? 0u : wbase + 64u;
+    }
+#ifdef TSQ_STATS
+    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[0] = st_[0]; g_enc_stats[1] = TSQ_TOTAL(); }
+#endif
+}
+
+__device__ __forceinline__ void stage_twins(uint32_t n, lds_u8_t* lds, uint32_t lane)
+{
+    volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
+    lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
+    const uint32_t n_tiles = (n >> 6) + 3u;
+    uint32_t h_m1 = 0xFFFFFFFFu, h_m2 = 0xFFFFFFFFu, h_m3 = 0xFFFFFFFFu;   // hashes of tiles t-1 .. t-3 (per lane)
+    uint32_t hashed_seen = 0;
+#ifdef TSQ_STATS
+    unsigned long long st_[32] = {0};
+#endif
+    TSQ_BEGIN();
+    for (uint32_t t = 0; t < n_tiles; ++t) {
+        if (!stage_wait_seen(ctl, kCtlHashed, t + 1u, hashed_seen, 0)) break;
         volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
         volatile lds_u32_t* rec_m1 = recs + ((t + StageCfg::R - 1u) % StageCfg::R) * StageCfg::REC_WORDS;
         volatile lds_u32_t* rec_m2 = recs + ((t + StageCfg::R - 2u) % StageCfg::R) * StageCfg::REC_WORDS;
         volatile lds_u32_t* rec_m3 = recs + ((t + StageCfg::R - 3u) % StageCfg::R) * StageCfg::REC_WORDS;
-        // The bucket's owner: the most recent lane of tiles t-1 .. t-3 with this folded hash (tile t-3 has tile t's id; nothing of
-        // tile t is in the image yet).  Then the entries of tile t-3 retire, unless a later tile has taken the bucket over.
-        const uint32_t before = owner[hf];
-        if (t >= 3u && ((uint32_t)owner[h_m3 & StageCfg::OWN_MASK] >> 6) == id) owner[h_m3 & StageCfg::OWN_MASK] = 0;
-        owner[hf] = (uint8_t)tag;
-        const uint32_t after = owner[hf];
+        volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
+        const uint32_t h = arr[kAH * 64];
+        const uint32_t own = arr[kAOwn * 64];
+        const uint32_t before = own & 0xFFu;
+        const uint32_t id = (own >> 8) & 3u;
+        const uint32_t id_m1 = id == 1u ? 3u : id - 1u; // the id of tile t-1 (the third one is tile t-2's)
         // ---- twins in the three previous tiles (t-1, t-2: the parser's business; t-3: MATCH folds its visited lanes into the
         // candidates; older tiles are in the table).  If the owner's hash is this lane's hash, this lane's twins are the owner and
         // the owner's own twins (already exact, by induction): no search.  If it is another hash (a fold collision: 192 live
@@ -204,7 +248,7 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
         // twins inside the tile: for each lane the mask of EARLIER lanes with the same hash
         uint64_t twin_in = 0, twins_here = 0;
         {
-            uint64_t shared = __ballot(after != (uint8_t)tag);
+            uint64_t shared = __ballot((own & 0x1000u) != 0u);
             while (shared) {
                 TSQ_CNT(22, 1);
                 const uint32_t hl = rdlane(h, lsb64(shared));
@@ -226,29 +270,16 @@ __device__ __forceinline__ void stage_scan(const uint8_t* src, uint64_t avail, u
                 maybe &= ~grp_cur;
             }
         }
-        {
-            u32x4_t v; v.x = w16.x; v.y = w16.y; v.z = w16.z; v.w = w16.w;
-            *(volatile lds_u32x4_t*)(rec + StageCfg::W16 + lane * 4u) = v;
-            // the tile's 64 input bytes join the window ring MATCH takes candidate bytes from
-            if (WINDOW && (lane & 15u) == 0u) {
-                *(volatile lds_u32x4_t*)(lds + StageCfg::off_win + wbase + lane) = v;
-                if (wbase == 0u && lane < 32u) *(volatile lds_u32x4_t*)(lds + StageCfg::off_win + StageCfg::WIN + lane) = v;
-            }
-        }
         if (lane == 0) { rec[0] = (uint32_t)twins_here; rec[1] = (uint32_t)(twins_here >> 32); }
-        volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
-        arr[kAH * 64] = h;
         arr[kATin * 64] = (uint32_t)twin_in;  arr[(kATin + 1) * 64] = (uint32_t)(twin_in >> 32);
         arr[kATp1 * 64] = (uint32_t)twin_p1;  arr[(kATp1 + 1) * 64] = (uint32_t)(twin_p1 >> 32);
         arr[kATp2 * 64] = (uint32_t)twin_p2;  arr[(kATp2 + 1) * 64] = (uint32_t)(twin_p2 >> 32);
         arr[kATp3 * 64] = (uint32_t)twin_p3;  arr[(kATp3 + 1) * 64] = (uint32_t)(twin_p3 >> 32);
         stage_publish(ctl, 2, t + 1u, lane);
         h_m3 = h_m2; h_m2 = h_m1; h_m1 = h;
-        id = id == 3u ? 1u : id + 1u;
-        wbase = wbase + 64u == StageCfg::WIN ? 0u : wbase + 64u;
     }
 #ifdef TSQ_STATS
-    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[0] = st_[0]; g_enc_stats[1] = TSQ_TOTAL(); g_enc_stats[32] = st_[20]; g_enc_stats[33] = st_[21]; g_enc_stats[34] = st_[22]; }
+    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[48] = st_[0]; g_enc_stats[49] = TSQ_TOTAL(); g_enc_stats[32] = st_[20]; g_enc_stats[33] = st_[21]; g_enc_stats[34] = st_[22]; }
 #endif
 }
 
@@ -1072,7 +1103,8 @@ __global__ __launch_bounds__(StageCfg::THREADS) void enc_stage_kernel(const uint
     if (role == 0) stage_walk<EXT, WINDOW>(src, avail, n, lds3, lane);
     else if (role == 6) stage_account(n, lds3, lane);
     else if (role == 8) stage_commit(n, table, lds3, lane);
-    else if (role == 3) stage_scan<WINDOW>(src, avail, n, lds3, lane);
+    else if (role == 3) stage_hash<WINDOW>(src, avail, n, lds3, lane);
+    else if (role == 9) stage_twins(n, lds3, lane);
     else if (role == 2) stage_match<EXT, WINDOW>(src, avail, n, table, lds3, lane);
     else if (role == 1 || role == 7) stage_orbit<EXT>(n, lds3, lane, role == 7 ? 1u : 0u);
     else if (role == 4) stream_emitter<StageCfg>(src, avail, out, lds3, lane, b, sizes, status);

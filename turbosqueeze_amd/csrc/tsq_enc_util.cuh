@@ -8,7 +8,7 @@ namespace tsq {
 
 // Instrumented builds (-DTSQ_STATS, make stats): block 0 publishes cycle and event counters.
 #ifdef TSQ_STATS
-__device__ unsigned long long g_enc_stats[48];
+__device__ unsigned long long g_enc_stats[64];
 #define TSQ_T0() unsigned long long t0_ = __builtin_amdgcn_s_memtime()
 #define TSQ_ACC(slot) do { unsigned long long t1_ = __builtin_amdgcn_s_memtime(); st_[slot] += t1_ - t0_; t0_ = t1_; } while (0)
 #define TSQ_CNT(slot, v) st_[slot] += (v)

@@ -436,9 +436,9 @@ extern "C" int tsqa_measure_copy(tsqa_ctx* c, size_t bytes, int reps, double* be
 
 #ifdef TSQ_STATS
 // instrumented builds only: counters published by block 0 of the last encode / decode launch
-extern "C" int tsqa_debug_stats(unsigned long long* enc48, unsigned long long* dec16)
+extern "C" int tsqa_debug_stats(unsigned long long* enc64, unsigned long long* dec16)
 {
-    if (enc48 && hipMemcpyFromSymbol(enc48, HIP_SYMBOL(tsq::g_enc_stats), 48 * sizeof(unsigned long long)) != hipSuccess) return TSQA_ERR_HIP;
+    if (enc64 && hipMemcpyFromSymbol(enc64, HIP_SYMBOL(tsq::g_enc_stats), 64 * sizeof(unsigned long long)) != hipSuccess) return TSQA_ERR_HIP;
     if (dec16 && hipMemcpyFromSymbol(dec16, HIP_SYMBOL(tsq::g_dec_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return TSQA_ERR_HIP;
     return TSQA_OK;
 }
