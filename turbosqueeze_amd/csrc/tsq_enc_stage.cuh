@@ -33,7 +33,7 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4_t lds_u32x4_t;
 
 struct StageCfg {
-    static constexpr uint32_t THREADS = 640;                      // ten wavefronts
+    static constexpr uint32_t THREADS = 704;                      // eleven wavefronts
     static constexpr uint32_t EQ = 64, EV_WORDS = 4;              // events between WALK and ACCOUNT
     static constexpr uint32_t Q = 16;                             // items between ACCOUNT and BUILDER
     static constexpr uint32_t ITEM_WORDS = 80;
@@ -64,7 +64,7 @@ enum : uint32_t { kAH = 0, kATin = 1, kATp1 = 3, kATp2 = 5, kASpan = 7, kALane =
 // events between WALK and ACCOUNT, and their ctl words (10 events produced, 11 consumed, 12 queries answered, 13 the answer,
 // 14 the tile ACCOUNT works on: the tiles before it are accounted)
 enum : uint32_t { kEvSeg = 1, kEvHaz = 2, kEvEnd = 3 };
-enum : uint32_t { kCtlEvHead = 10, kCtlEvTail = 11, kCtlReplies = 12, kCtlReplyValue = 13, kCtlAccounted = 14, kCtlOrbitOdd = 15, kCtlCommitted = 33, kCtlHashed = 34 };
+enum : uint32_t { kCtlEvHead = 10, kCtlEvTail = 11, kCtlReplies = 12, kCtlReplyValue = 13, kCtlAccounted = 14, kCtlOrbitOdd = 15, kCtlCommitted = 33, kCtlHashed = 34, kCtlMatchedOdd = 35 };
 
 // Instrumented builds time only the spin loops (and only when they actually spin): s_memtime costs a few
 // hundred cycles, so finer timing distorts the pipeline it measures.  busy = total - waited.
@@ -285,21 +285,21 @@ __device__ __forceinline__ void stage_twins(uint32_t n, lds_u8_t* lds, uint32_t 
 
 // --------------------------------------------------------------------------------------------- MATCH
 template <bool EXT, bool WINDOW>
-__device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, uint32_t n, uint16_t* table, lds_u8_t* lds, uint32_t lane)
+__device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, uint32_t n, uint16_t* table, lds_u8_t* lds, uint32_t lane, uint32_t parity)
 {
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
     constexpr uint32_t kDMin = EXT ? 128u : 64u;
     const uint32_t tail_from = n >= 5u ? n - 5u : 0u;
     const uint32_t n_tiles = (n >> 6) + 3u;
-    uint32_t h_m1 = 0, h_m2 = 0, h_m3 = 0;
-    uint32_t wbase = 0;                                // (t * 64) % WIN
+    // two MATCH wavefronts take the even and the odd tiles (nothing is carried from tile to tile)
+    uint32_t wbase = parity << 6;                      // (t * 64) % WIN
     uint32_t scanned_seen = 0, committed_seen = 0;
 #ifdef TSQ_STATS
     unsigned long long st_[32] = {0};
 #endif
     TSQ_BEGIN();
-    for (uint32_t t = 0; t < n_tiles; ++t) {
+    for (uint32_t t = parity; t < n_tiles; t += 2u) {
         MREG_BEGIN(10);
         if (!stage_wait_seen(ctl, 2, t + 1u, scanned_seen, 2)) break;
         volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
@@ -403,13 +403,12 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         const bool twin_l = (twin_in | twin_p1) != 0ull || tp2_any != 0u;
         arr[kASpan * 64] = span_nat | (hard_l ? 0x100u : 0u) | (twin_l ? 0x200u : 0u) | (certain ? 0x400u : 0u) | (neart ? 0x800u : 0u) | (k0 << 16);
         arr[kALane * 64] = cand0 | (nib << 24);
-        stage_publish(ctl, 3, t + 1u, lane);
+        stage_publish(ctl, parity ? kCtlMatchedOdd : 3u, t + 1u, lane);
         MREG_END(14);
-        h_m3 = h_m2; h_m2 = h_m1; h_m1 = h;
-        wbase = wbase + 64u == StageCfg::WIN ? 0u : wbase + 64u;
+        wbase = wbase + 128u >= StageCfg::WIN ? wbase + 128u - StageCfg::WIN : wbase + 128u;
     }
 #ifdef TSQ_STATS
-    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[2] = st_[2]; g_enc_stats[3] = st_[3]; g_enc_stats[4] = TSQ_TOTAL(); g_enc_stats[13] = st_[13]; g_enc_stats[14] = st_[14]; g_enc_stats[35] = st_[20]; g_enc_stats[36] = st_[21]; }
+    if (blockIdx.x == 0 && lane == 0 && parity == 0u) { g_enc_stats[2] = st_[2]; g_enc_stats[3] = st_[3]; g_enc_stats[4] = TSQ_TOTAL(); g_enc_stats[13] = st_[13]; g_enc_stats[14] = st_[14]; g_enc_stats[35] = st_[20]; g_enc_stats[36] = st_[21]; }
 #endif
 }
 
@@ -511,7 +510,7 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
                 }
             }
         }
-        if (!stage_wait(ctl, 3, t + 1u, 6)) break;
+        if (!stage_wait(ctl, parity ? kCtlMatchedOdd : 3u, t + 1u, 6)) break;
         uint32_t sw = arr[kASpan * 64];
         if (fix) { sw = fix_sw; arr[kASpan * 64] = fix_sw; arr[kALane * 64] = fix_lw; }
         if (clear_tp2) { sw |= 0x1000u; arr[kASpan * 64] = sw; }      // (SCAN's masks stay as they are: later tiles inherit from them)
@@ -1105,7 +1104,7 @@ __global__ __launch_bounds__(StageCfg::THREADS) void enc_stage_kernel(const uint
     else if (role == 8) stage_commit(n, table, lds3, lane);
     else if (role == 3) stage_hash<WINDOW>(src, avail, n, lds3, lane);
     else if (role == 9) stage_twins(n, lds3, lane);
-    else if (role == 2) stage_match<EXT, WINDOW>(src, avail, n, table, lds3, lane);
+    else if (role == 2 || role == 10) stage_match<EXT, WINDOW>(src, avail, n, table, lds3, lane, role == 10 ? 1u : 0u);
     else if (role == 1 || role == 7) stage_orbit<EXT>(n, lds3, lane, role == 7 ? 1u : 0u);
     else if (role == 4) stream_emitter<StageCfg>(src, avail, out, lds3, lane, b, sizes, status);
     else stream_builder<StageCfg>(lds3, lane);
