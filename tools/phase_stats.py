@@ -39,7 +39,7 @@ print("  HASH    total=%.0f waited(ring)=%.0f busy=%.0f" % (e[1] / T, e[0] / T, 
 print("  TWINS   total=%.0f waited(hash)=%.0f busy=%.0f" % (e[49] / T, e[48] / T, (e[49] - e[48]) / T))
 print("          unsure lanes per tile=%.2f, settle rounds per tile=%.2f, in-tile group rounds per tile=%.2f" % (e[32] / T, e[33] / T, e[34] / T))
 print("  MATCH   total=%.0f waited(scan)=%.0f waited(parser)=%.0f busy=%.0f" % (e[4] / T, e[2] / T, e[3] / T, (e[4] - e[2] - e[3]) / T))
-print("          length-extension rounds per tile=%.2f (from the window ring %.2f)" % (e[36] / T, e[35] / T))
+print("          length-extension rounds per tile=%.2f (from the window ring %.2f), tiles classified twice (even wave)=%.3f" % (e[36] / T, e[35] / T, e[50] / T))
 print("  COMMIT  total=%.0f waited=%.0f busy=%.0f" % (e[46] / T, e[45] / T, (e[46] - e[45]) / T))
 print("  ORBIT   total=%.0f waited=%.0f busy=%.0f" % (e[7] / T, e[6] / T, (e[7] - e[6]) / T))
 print("  WALK    total=%.0f waited(orbit)=%.0f waited(events)=%.0f waited(answers)=%.0f busy=%.0f  queries per tile=%.3f" % (e[10] / T, e[8] / T, e[9] / T, e[40] / T, (e[10] - e[8] - e[9] - e[40]) / T, e[20] / T))

@@ -22,6 +22,9 @@
 // candidate, which is what the reference's table would hold (tsq_encode.cpp:76-79), or keeps the
 // gathered candidate when no twin was visited.
 #pragma once
+#ifndef TSQ_LATE_FIX
+#define TSQ_LATE_FIX 1
+#endif
 
 #include "tsq_common.cuh"
 #include "tsq_enc_util.cuh"
@@ -98,6 +101,13 @@ __device__ __forceinline__ bool stage_ready(lds_u32_t* ctl, uint32_t word, uint3
     asm volatile("" ::: "memory");
     return seen >= need;
 }
+__device__ __forceinline__ bool stage_spin_tight(lds_u32_t* ctl, uint32_t word, uint32_t need)
+{
+    for (;;) {
+        if (stage_ready(ctl, word, need)) return true;
+        if (uniform(__hip_atomic_load(&ctl[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0u) return false;
+    }
+}
 __device__ __forceinline__ bool stage_spin(lds_u32_t* ctl, uint32_t word, uint32_t need)
 {
     for (;;) {
@@ -122,6 +132,11 @@ __device__ __forceinline__ bool stage_spin_seen(lds_u32_t* ctl, uint32_t word, u
 #define stage_wait_seen(ctl, word, need, seen, slot) ((seen) >= (need) || [&]() { bool ok_; TSQ_WAITED(slot, ok_ = stage_spin_seen(ctl, word, need, seen)); return ok_; }())
 #else
 #define stage_wait_seen(ctl, word, need, seen, slot) ((seen) >= (need) || stage_spin_seen(ctl, word, need, seen))
+#endif
+#ifdef TSQ_STATS
+#define stage_wait_tight(ctl, word, need, slot) (stage_ready(ctl, word, need) || [&]() { bool ok_; TSQ_WAITED(slot, ok_ = stage_spin_tight(ctl, word, need)); return ok_; }())
+#else
+#define stage_wait_tight(ctl, word, need, slot) (stage_ready(ctl, word, need) || stage_spin_tight(ctl, word, need))
 #endif
 #ifdef TSQ_STATS
 #define stage_wait(ctl, word, need, slot) (stage_ready(ctl, word, need) || [&]() { bool ok_; TSQ_WAITED(slot, ok_ = stage_spin(ctl, word, need)); return ok_; }())
@@ -324,7 +339,7 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         // keep theirs.
         uint32_t tv = tv_old;
         if (t >= 3u) {
-            if (!stage_wait(ctl, 5, t - 2u, 3)) break;
+            if (!stage_wait_tight(ctl, 5, t - 2u, 3)) break;
             const uint32_t slot = 16u + 2u * ((t - 3u) & 7u);
             const uint32_t vis_lo = uniform(__hip_atomic_load(&ctl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             const uint32_t vis_hi = uniform(__hip_atomic_load(&ctl[slot + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -479,7 +494,7 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
         //      All of this needs only SCAN's part of the record, so it runs while MATCH is still gathering tile t.
         uint32_t fix_sw = 0, fix_lw = 0;
         bool fix = false, clear_tp2 = false;
-        if (t >= 2u) {
+        if (TSQ_LATE_FIX && t >= 2u) {
             if (!stage_wait_seen(ctl, 2, t + 1u, scanned_seen, 6)) break;
             const uint32_t tp2_lo = arr[kATp2 * 64], tp2_hi = arr[(kATp2 + 1) * 64];
             const uint32_t nearer = arr[kATin * 64] | arr[(kATin + 1) * 64] | arr[kATp1 * 64] | arr[(kATp1 + 1) * 64];
@@ -510,7 +525,7 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
                 }
             }
         }
-        if (!stage_wait(ctl, parity ? kCtlMatchedOdd : 3u, t + 1u, 6)) break;
+        if (!stage_wait_tight(ctl, parity ? kCtlMatchedOdd : 3u, t + 1u, 6)) break;
         uint32_t sw = arr[kASpan * 64];
         if (fix) { sw = fix_sw; arr[kASpan * 64] = fix_sw; arr[kALane * 64] = fix_lw; }
         if (clear_tp2) { sw |= 0x1000u; arr[kASpan * 64] = sw; }      // (SCAN's masks stay as they are: later tiles inherit from them)
@@ -586,7 +601,6 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
     volatile lds_u32_t* evq = (volatile lds_u32_t*)(lds + StageCfg::off_evq);
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
-    constexpr uint32_t kDMin = EXT ? 128u : 64u;
     const uint32_t tail_from = uniform(n >= 5u ? n - 5u : 0u);
 
     uint32_t ev_head = 0, ev_tail_seen = 0, n_query = 0;
@@ -656,7 +670,6 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
             const uint64_t hard = __ballot((spanword & 0x100u) != 0u);
             const uint64_t near_m = __ballot((spanword & 0x800u) != 0u);
             const uint64_t certain_m = __ballot((spanword & 0x400u) != 0u);
-            const uint32_t span_nat = spanword & 0xFFu;
             uint64_t Vacc = 0;                   // visited lanes not yet handed to ACCOUNT
             // a twin visited in the two previous tiles: fixed for the whole tile (kept per lane, it joins the in-tile test)
             const uint32_t prev_hit = (tp1_lo & (uint32_t)vall_p1) | (tp1_hi & (uint32_t)(vall_p1 >> 32)) |

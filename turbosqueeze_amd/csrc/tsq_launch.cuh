@@ -16,6 +16,7 @@
 #include "tsq_enc_stage.cuh"
 #ifdef TSQ_AB_VARIANTS
 #include "ab/tsq_dec_ring.cuh"
+#include "ab/tsq_enc_stage5.cuh"
 #endif
 
 namespace tsq {
@@ -56,7 +57,26 @@ inline int launch_encode_kernels(tsqa_ctx* c, const uint8_t* in, size_t n, size_
         else     TSQ_LAUNCH_ENC(enc_serial_kernel<false>, 64, 0);
         return 0;
     }
-    if (v >= 2 && v <= 5) { c->set_error("kernel variant %d is not built", v); return TSQA_ERR_ARG; }
+#ifdef TSQ_AB_VARIANTS
+    if (v == 5) {                       // round 2's five-wave staged encoder, frozen (ab/tsq_enc_stage5.cuh)
+        static std::atomic<uint64_t> ab_devices{0};
+        const void* const fns[4] = {reinterpret_cast<const void*>(r02::enc_stage_kernel<true, true>), reinterpret_cast<const void*>(r02::enc_stage_kernel<false, true>),
+                                    reinterpret_cast<const void*>(r02::enc_stage_kernel<true, false>), reinterpret_cast<const void*>(r02::enc_stage_kernel<false, false>)};
+        const uint32_t bytes[4] = {r02::StageCfg::total, r02::StageCfg::total, r02::StageCfg::total_lean, r02::StageCfg::total_lean};
+        if (int rc = raise_lds_limit(c, ab_devices, fns, bytes)) return rc;
+        if (nb > (uint32_t)c->n_cus) {
+            if (ext) TSQ_LAUNCH_ENC((r02::enc_stage_kernel<true, false>), 320, r02::StageCfg::total_lean);
+            else     TSQ_LAUNCH_ENC((r02::enc_stage_kernel<false, false>), 320, r02::StageCfg::total_lean);
+        } else {
+            if (ext) TSQ_LAUNCH_ENC((r02::enc_stage_kernel<true, true>), 320, r02::StageCfg::total);
+            else     TSQ_LAUNCH_ENC((r02::enc_stage_kernel<false, true>), 320, r02::StageCfg::total);
+        }
+        return 0;
+    }
+#else
+    if (v == 5) { c->set_error("kernel variant %d lives in the A/B library only (make ab)", v); return TSQA_ERR_ARG; }
+#endif
+    if (v >= 2 && v <= 4) { c->set_error("kernel variant %d is not built", v); return TSQA_ERR_ARG; }
     // five-wave staged pipeline: scan + match + orbit + parser + builder.  More blocks than CUs: the lean layout (no input
     // window in LDS, candidate bytes from L2) lets two blocks share a CU; each is a little slower, together they are faster.
     const bool lean = v == 6 || (v == 0 && nb > (uint32_t)c->n_cus);
