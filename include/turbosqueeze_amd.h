@@ -137,7 +137,11 @@ typedef struct tsqa_frame {
 } tsqa_frame;
 
 /* tsqa_decode_blocks_async: decode n_blocks streams described by d_frames (device memory).  Replaces tsqDecode
- * per owned block (tsq_threads.cpp:590).  *d_status becomes TSQA_ERR_STREAM on a malformed stream. */
+ * per owned block (tsq_threads.cpp:590).  *d_status becomes TSQA_ERR_STREAM on a malformed stream.
+ * Trust: the descriptors may be taken from an untrusted container.  The kernels refuse (TSQA_ERR_STREAM) a stream_len
+ * below 3 or above TSQ_OUTPUT_SZ and an out_len above TSQ_BLOCK_SZ, and never read a stream beyond stream_len bytes nor write
+ * a block beyond out_len bytes.  stream_at and out_at are the CALLER's responsibility: stream_at + stream_len must lie inside
+ * d_streams and out_at + out_len inside d_out (the library has no way to know the sizes of those allocations). */
 int tsqa_decode_blocks_async(tsqa_ctx *ctx, const void *d_streams, const tsqa_frame *d_frames, uint32_t n_blocks,
                              void *d_out, int32_t *d_status, void *hip_stream);
 
@@ -167,11 +171,12 @@ int tsqa_profile_read_calls(tsqa_ctx *ctx, double *compress_ms, uint32_t *compre
  * kernel is priced against the HBM roofline. */
 int tsqa_measure_copy(tsqa_ctx *ctx, size_t bytes, int reps, double *best_gbps, double *median_gbps);
 
-/* Kernel variant selection.  Encoder: 0 = default (five-wave staged encoder; its lean layout by itself when there are
+/* Kernel variant selection.  Encoder: 0 = default (eleven-wave staged encoder; its lean layout by itself when there are
  * more blocks than CUs), 1 = serial kernel (one lane walks the block; correctness baseline), 6 = force the lean layout
- * (two blocks per CU), 7 = never lean.  Decoder: 0 = default (byte-lane decoder), 1 = serial kernel.  The superseded
- * kernel generations (encoder 2-5; decoder 2, 8, 9) exist only in the A/B library built by `make ab`; the product
- * library rejects them. */
+ * (two blocks per CU), 7 = never lean.  Decoder: 0 = default (byte-lane decoder; on two workgroups per block when a
+ * launch has at most half as many blocks as the device has CUs), 1 = serial kernel, 3 = always two workgroups per block,
+ * 4 = always one.  Superseded kernel generations (encoder 5 = round 2's five-wave encoder; decoder 8, 9 = round 1's
+ * byte-granular ring decoder) exist only in the A/B library built by `make ab`; the product library rejects them. */
 void tsqa_set_kernel_variant(tsqa_ctx *ctx, int encode_variant, int decode_variant);
 
 /* =====================================================================================

@@ -83,4 +83,23 @@ if "--no-time" not in sys.argv:
         em, en, dm, dn = codec.profile_read()
         assert torch.equal(back, src)
         print(f"TIME text 1e9 ext={ext}: encode kernel {em / max(en, 1):.2f} ms, decode kernel {dm / max(dn, 1):.3f} ms, ratio {blob.numel() / len(host):.4f}", flush=True)
+if "--no-time" not in sys.argv:
+    # few blocks: the two-workgroup decoder (variant 3) against the one-workgroup one (variant 4)
+    for nb in (30, 60, 120):
+        host = tsq.synth.text(nb * B, 2)
+        src = torch.from_numpy(host).cuda()
+        blob = codec.compress(src, 0)
+        line = f"TIME decode {nb} blocks:"
+        for dv in (4, 3):
+            codec.set_variant(0, dv)
+            back = codec.decompress(blob)
+            codec.profile_read()
+            for _ in range(5):
+                back = codec.decompress(blob)
+            torch.cuda.synchronize()
+            em, en, dm, dn = codec.profile_read()
+            assert torch.equal(back, src), f"decode variant {dv} differs"
+            line += f"  variant {dv}: {dm / max(dn, 1):.3f} ms ({len(host) / (dm / max(dn, 1)) / 1e6:.1f} GB/s)"
+        codec.set_variant(0, 0)
+        print(line, flush=True)
 sys.exit(1 if bad else 0)

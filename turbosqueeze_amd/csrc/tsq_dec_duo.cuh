@@ -1,0 +1,517 @@
+// tsq_dec_duo.cuh -- block decoder on TWO workgroups per block (kernel variant 3; chosen by itself when a launch has at most half as
+// many blocks as the device has CUs -- every GPU of a multi-GPU enwik9 job).
+//
+// A block's decode is two serial chains (tsq_decode.cpp:62-88): the PARSE chain -- where a chunk of the stream starts follows from
+// where the previous one ended -- and the COPY chain -- a chunk's bytes may copy the 64 KiB before them.  dec_sym_kernel runs both
+// on one CU, one after the other per chunk.  Here they run on two CUs of the same XCD, side by side:
+//
+//   PARSE workgroup  phases P0..P4 of tsq_dec_sym.cuh (stage the chunk, speculative group parse at every offset, pointer doubling,
+//                    the chain from the known start, one lane per group -> pair words and output offsets), then hands the chunk's
+//                    pair words, group output offsets and a header to the COPY workgroup through a four-deep ring of records in
+//                    global memory (they stay in the XCD's L2) and moves on to the next chunk at once.
+//   COPY workgroup   phase P5 of tsq_dec_sym.cuh (pairs -> records -> bytes, history in the 64 KiB LDS ring) and the stores to HBM.
+//
+// Workgroup w runs on XCD w % 8 (the hardware deals workgroups round-robin): w -> (xcd = w % 8, slot = w / 8), role = slot & 1,
+// block = (slot / 2) * 8 + xcd puts a block's two workgroups on one XCD, the PARSE one dispatched first.  Every wait is bounded and
+// also ends when another block has reported an error.
+#pragma once
+
+#include <type_traits>
+
+#include "tsq_common.cuh"
+#include "tsq_dec_common.cuh"
+#include "tsq_dec_sym.cuh"
+
+namespace tsq {
+
+struct DuoCfg {
+    static constexpr uint32_t SLOTS = 4;                                   // chunk records in flight per block
+    static constexpr uint32_t HDR = 8;                                     // header words: 0 sp, 1 op, 2 groups, 3 next op, 4 flags, 5 next sp
+    static constexpr uint32_t REC_WORDS = ((HDR + 5 * SymCfg::MAXG) + 63u) & ~63u;
+    static constexpr uint32_t FLAG_STRIDE = 64;                            // u32 words per block: [0] chunks produced, [32] chunks consumed
+    static constexpr uint32_t kLast = 1, kError = 2;
+    static constexpr uint32_t kAbort = 0xFFFFFFFFu;
+    static constexpr uint32_t kSpinLimit = 1u << 24;                       // polls (with s_sleep) before a wait gives up: seconds
+};
+
+__device__ __forceinline__ uint32_t duo_load_acquire(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void duo_store_release(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ------------------------------------------------------------------------------------------------------------------ PARSE
+__device__ __forceinline__ void duo_parse(const uint8_t* __restrict__ in, uint32_t in_len, uint32_t size, uint32_t ext,
+                                          uint32_t* __restrict__ ring_g, uint32_t* __restrict__ flags, int32_t* __restrict__ status, uint8_t* lds)
+{
+    using C = SymCfg;
+    uint8_t* const s_raw = lds + SymLds::sbuf;
+    uint8_t* const j1 = lds + SymLds::j1;
+    uint16_t* const j2 = reinterpret_cast<uint16_t*>(lds + SymLds::j2);
+    uint16_t* const j4 = reinterpret_cast<uint16_t*>(lds + SymLds::j4);
+    uint16_t* const j8 = reinterpret_cast<uint16_t*>(lds + SymLds::j8);
+    uint16_t* const j16 = reinterpret_cast<uint16_t*>(lds + SymLds::j16);
+    uint16_t* const gstart = reinterpret_cast<uint16_t*>(lds + SymLds::gstart);
+    uint16_t* const glen = reinterpret_cast<uint16_t*>(lds + SymLds::glen);
+    uint32_t* const gout = reinterpret_cast<uint32_t*>(lds + SymLds::gout);
+    uint32_t* const pairs = reinterpret_cast<uint32_t*>(lds + SymLds::pairs);
+    uint16_t* const sn = reinterpret_cast<uint16_t*>(lds + SymLds::sn);
+    uint32_t* const wsum = reinterpret_cast<uint32_t*>(lds + SymLds::wsum);
+    uint32_t* const misc = reinterpret_cast<uint32_t*>(lds + SymLds::misc);
+    uint16_t* const lut = reinterpret_cast<uint16_t*>(lds + SymLds::lut);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+
+    if (size == 0u) return;                              // (an empty block has no chunks: neither workgroup has anything to do)
+    if (tid == 0) misc[4] = 0;
+    { uint32_t sl, ol; pair_lens(tid & 255u, tid >> 8, 0u, sl, ol); lut[tid] = (uint16_t)sl; }
+    uint32_t sp = 3, op = 0, k = 0;
+    uint4 pre = make_uint4(0, 0, 0, 0);
+    auto prefetch = [&](uint32_t at) {
+        const uint32_t avail = in_len - at;
+        const uint32_t lim = avail < C::S + C::SPAD ? avail : C::S + C::SPAD;
+        pre = make_uint4(0, 0, 0, 0);
+        if (tid < C::SWORDS && (tid << 4) + 16u <= lim) __builtin_memcpy(&pre, in + at + (tid << 4), 16);
+    };
+    prefetch(sp);
+    __syncthreads();
+
+    while (op < size) {
+        // ---------------- P0: the chunk (loaded a chunk ago) goes to LDS.  sbuf[k] = in[sp + k]; zeros beyond the stream.
+        const uint32_t avail = in_len - sp;
+        const uint32_t slim = avail < C::S ? avail : C::S;
+        uint8_t* const sbuf = s_raw;
+        if (tid < C::SWORDS) {
+            uint4 w = pre;
+            const uint32_t lim = avail < C::S + C::SPAD ? avail : C::S + C::SPAD, o = tid << 4;
+            if (o < lim && o + 16u > lim) {                                       // the stream's last, partial word (once per block)
+                uint32_t b[4] = {0, 0, 0, 0};
+                for (uint32_t q = 0; o + q < lim; ++q) b[q >> 2] |= (uint32_t)in[sp + o + q] << (8u * (q & 3u));
+                w = make_uint4(b[0], b[1], b[2], b[3]);
+            }
+            *reinterpret_cast<uint4*>(s_raw + (tid << 4)) = w;
+        }
+        if (tid == 0) { misc[0] = 0; misc[1] = 0; misc[2] = 0xFFFFFFFFu; misc[3] = 0xFFFFFFFFu; misc[5] = 0; }
+        __syncthreads();
+        // ---------------- P1 + P2: speculative group parse at every offset, then next^2 .. next^16 (tsq_dec_sym.cuh)
+        {
+            uint32_t x[C::PER], y[C::PER], c[C::PER];
+#pragma unroll
+            for (uint32_t q = 0; q < C::PER; ++q) { const uint32_t o = tid + q * C::T; c[q] = sbuf[o]; x[q] = o + 1u; }
+#pragma unroll
+            for (uint32_t pr = 0; pr < 4; ++pr) {
+#pragma unroll
+                for (uint32_t q = 0; q < C::PER; ++q) y[q] = sbuf[x[q]];
+#pragma unroll
+                for (uint32_t q = 0; q < C::PER; ++q) y[q] = lut[(((c[q] >> (6u - 2u * pr)) & 3u) << 8) | y[q]];
+#pragma unroll
+                for (uint32_t q = 0; q < C::PER; ++q) x[q] += y[q];
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < C::PER; ++q) { const uint32_t o = tid + q * C::T; j1[o] = (uint8_t)(x[q] - o); x[q] = o < slim ? x[q] : C::TERM; }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t q = 0; q < C::PER; ++q) { const uint32_t a = x[q] < slim ? x[q] : 0u; y[q] = a + j1[a]; }
+#pragma unroll
+            for (uint32_t q = 0; q < C::PER; ++q) { x[q] = x[q] < slim ? y[q] : C::TERM; j2[tid + q * C::T] = (uint16_t)x[q]; }
+            __syncthreads();
+            const uint16_t* srcj = j2;
+            uint16_t* const dsts[3] = {j4, j8, j16};
+#pragma unroll
+            for (uint32_t d = 0; d < 3; ++d) {
+#pragma unroll
+                for (uint32_t q = 0; q < C::PER; ++q) y[q] = srcj[x[q] < slim ? x[q] : 0u];
+#pragma unroll
+                for (uint32_t q = 0; q < C::PER; ++q) { x[q] = x[q] < slim ? y[q] : C::TERM; dsts[d][tid + q * C::T] = (uint16_t)x[q]; }
+                __syncthreads();
+                srcj = dsts[d];
+            }
+        }
+        // ---------------- P3: one lane follows next^16 from the chunk start
+        if (tid == 0) {
+            uint32_t x = 0, q = 0;
+            while (x < slim && q < C::MAXSN) { sn[q++] = (uint16_t)x; x = j16[x]; }
+            misc[0] = q;
+            if (q >= C::MAXSN && x < slim) misc[4] = kErrStream;
+        }
+        __syncthreads();
+        const uint32_t nsn = misc[0];
+        // ---------------- P4: one lane per group
+        {
+            uint32_t x = C::TERM;
+            if (tid < nsn * C::HOP) {
+                x = sn[tid >> 4];
+                if (tid & 8u) x = x < slim ? j8[x] : C::TERM;
+                if (tid & 4u) x = x < slim ? j4[x] : C::TERM;
+                if (tid & 2u) x = x < slim ? j2[x] : C::TERM;
+                if (tid & 1u) x = x < slim ? (uint32_t)(x + j1[x]) : C::TERM;
+            }
+            uint32_t v = 0;
+            if (x < slim) {
+                gstart[tid] = (uint16_t)x;
+                const uint32_t c = sbuf[x];
+                uint32_t p = x + 1u, pw[4];
+#pragma unroll
+                for (uint32_t pr = 0; pr < 4; ++pr) {
+                    const uint32_t cc = (c >> (6u - 2u * pr)) & 3u;
+                    pw[pr] = p | (v << 13) | (cc << 30);
+                    uint32_t sl, ol;
+                    pair_lens(sbuf[p], cc, ext, sl, ol);
+                    p += sl;
+                    v += ol;
+                }
+                *reinterpret_cast<uint4*>(pairs + tid * 4u) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+                glen[tid] = (uint16_t)v;
+                if (p >= slim) { misc[1] = tid + 1u; misc[5] = p; }
+            }
+            const uint32_t incl = wave_scan_add(v);
+            if (lane == 63) wsum[wid] = incl;
+            __syncthreads();
+            const uint32_t totals = wave_scan_add(lane < C::T / 64u ? wsum[lane] : 0u);
+            const uint32_t before = wid ? (uint32_t)__builtin_amdgcn_readlane((int)totals, (int)wid - 1) : 0u;
+            const uint32_t excl = before + incl - v;
+            if (x < slim) {
+                gout[tid] = op + excl;
+                if (excl + 512u + 16u > C::OUTC) atomicMin(&misc[2], tid);
+                if (op + excl + v >= size) atomicMin(&misc[3], tid);
+            }
+        }
+        __syncthreads();
+        uint32_t ng = misc[1];
+        uint32_t next_sp, next_op;
+        bool last_chunk = false;
+        {
+            const uint32_t cut = misc[2], fin = misc[3];
+            if (fin != 0xFFFFFFFFu && fin < cut) { ng = fin + 1; last_chunk = true; next_sp = sp; next_op = size; }
+            else if (cut != 0xFFFFFFFFu) { ng = cut; next_sp = sp + gstart[cut]; next_op = gout[cut]; }
+            else { next_sp = sp + misc[5]; next_op = ng ? gout[ng - 1] + glen[ng - 1] : op; }
+        }
+        const bool bad = misc[4] != 0 || ng == 0 || (!last_chunk && next_sp >= in_len);
+        if (!bad && !last_chunk) prefetch(next_sp);
+        // ---------------- hand the chunk to the COPY workgroup
+        if (tid == 0) {
+            uint32_t give_up = 0, spins = 0;
+            for (;;) {
+                const uint32_t done = duo_load_acquire(flags + 32);
+                if (done == DuoCfg::kAbort || ((spins & 255u) == 255u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { give_up = 1; break; }
+                if (k - done < DuoCfg::SLOTS) break;
+                if (++spins > DuoCfg::kSpinLimit) { give_up = 2; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            misc[6] = give_up;
+        }
+        __syncthreads();
+        if (misc[6] != 0) { if (tid == 0 && misc[6] == 2) atomicMax(status, kErrStream); return; }
+        uint32_t* const rec = ring_g + (size_t)(k % DuoCfg::SLOTS) * DuoCfg::REC_WORDS;
+        if (!bad) {
+            for (uint32_t w = tid; w < 4u * ng; w += C::T) rec[DuoCfg::HDR + w] = pairs[w];
+            for (uint32_t w = tid; w < ng; w += C::T) rec[DuoCfg::HDR + 4u * C::MAXG + w] = gout[w];
+        }
+        if (tid == 0) {
+            rec[0] = sp; rec[1] = op; rec[2] = ng; rec[3] = next_op;
+            rec[4] = (last_chunk ? DuoCfg::kLast : 0u) | (bad ? DuoCfg::kError : 0u);
+            rec[5] = next_sp;
+        }
+        __syncthreads();                                 // every thread's record stores are complete (the barrier waits for them) ...
+        k++;
+        if (tid == 0) duo_store_release(flags, k);        // ... and thread 0 publishes them
+        if (bad) { if (tid == 0) atomicMax(status, kErrStream); return; }
+        op = next_op;
+        sp = next_sp;
+        if (last_chunk) break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------- COPY
+struct DuoCopyLds {
+    static constexpr uint32_t sbuf = 0;                                             // u8[S + SPAD + 16]
+    static constexpr uint32_t recw = sbuf + 16 * SymCfg::SWORDS;                     // u32[OUTC + 16] symbol records, then u16 byte entries over them
+    static constexpr uint32_t ent = recw;
+    static constexpr uint32_t plist = ent + 2 * (SymCfg::OUTC + 16);                // u16[OUTC] waiting lists
+    static constexpr uint32_t wsum = recw + 4 * (SymCfg::OUTC + 16);                // u32[16]
+    static constexpr uint32_t misc = wsum + 64;                                     // u32[16]
+    static constexpr uint32_t ring = (misc + 64 + 15) & ~15u;                       // u8[R + RPAD]
+    static constexpr uint32_t total = ring + SymCfg::R + SymCfg::RPAD;
+    static_assert(recw % 16 == 0 && plist % 16 == 0 && plist + 2 * SymCfg::OUTC <= wsum, "records, byte entries and waiting lists");
+};
+static_assert(DuoCopyLds::total <= 160 * 1024 && SymLds::total <= 160 * 1024, "LDS budget");
+
+__device__ __forceinline__ void duo_copy(const uint8_t* __restrict__ in, uint32_t in_len, uint32_t size, uint32_t ext, uint8_t* __restrict__ out,
+                                         const uint32_t* __restrict__ ring_g, uint32_t* __restrict__ flags, int32_t* __restrict__ status, uint8_t* lds)
+{
+    using C = SymCfg;
+    uint8_t* const sbuf = lds + DuoCopyLds::sbuf;
+    uint32_t* const recw = reinterpret_cast<uint32_t*>(lds + DuoCopyLds::recw);
+    uint32_t* const wsum = reinterpret_cast<uint32_t*>(lds + DuoCopyLds::wsum);
+    uint32_t* const misc = reinterpret_cast<uint32_t*>(lds + DuoCopyLds::misc);
+    uint8_t* const ring = lds + DuoCopyLds::ring;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    // ring address of output position p: (p + oskew) mod R, so that 16-byte words of the ring are 16-byte words of HBM
+    const uint32_t oskew = (uint32_t)((uintptr_t)out & 15u);
+    uint32_t ring_op = oskew;
+    uint32_t prev_op = 0, prev_len = 0, prev_ring = 0;
+    uint32_t k = 0;
+    if (size == 0u) return;
+    if (tid == 0) { misc[4] = 0; }
+
+    auto flush_image = [&]() {
+        // image bytes [prev_op, prev_op + prev_len) from the ring to HBM: head bytes up to the first aligned word, aligned
+        // 16-byte words, tail bytes
+        if (prev_len == 0) return;
+        const uint32_t head = (16u - (prev_ring & 15u)) & 15u;
+        const uint32_t hb = head < prev_len ? head : prev_len;
+        if (tid < hb) out[prev_op + tid] = ring[prev_ring + tid];
+        const uint32_t words = (prev_len - hb) >> 4;
+        uint32_t ra = prev_ring + hb; ra -= ra >= C::R ? C::R : 0u;
+        for (uint32_t w = tid; w < words; w += C::T) {
+            uint32_t a = ra + (w << 4); a -= a >= C::R ? C::R : 0u;
+            *reinterpret_cast<uint4*>(out + prev_op + hb + (w << 4)) = *reinterpret_cast<const uint4*>(ring + a);
+        }
+        const uint32_t tail_at = hb + (words << 4);
+        if (tid < prev_len - tail_at) { uint32_t a = ra + (words << 4) + tid; a -= a >= C::R ? C::R : 0u; out[prev_op + tail_at + tid] = ring[a]; }
+    };
+    uint4 pre = make_uint4(0, 0, 0, 0);
+    uint32_t pre_sp = 0xFFFFFFFFu;                                                    // the stream offset `pre` was loaded from
+    auto prefetch = [&](uint32_t at) {
+        const uint32_t avail = in_len - at;
+        const uint32_t lim = avail < C::S + C::SPAD ? avail : C::S + C::SPAD;
+        pre = make_uint4(0, 0, 0, 0);
+        if (tid < C::SWORDS && (tid << 4) + 16u <= lim) __builtin_memcpy(&pre, in + at + (tid << 4), 16);
+        pre_sp = at;
+    };
+    prefetch(3u);
+    __syncthreads();
+
+    for (;;) {
+        // ---------------- the previous chunk's bytes go to HBM while thread 0 waits for this chunk's record
+        flush_image();
+        if (tid == 0) {
+            uint32_t give_up = 0, spins = 0;
+            for (;;) {
+                const uint32_t made = duo_load_acquire(flags);
+                if (made > k) break;
+                if ((spins & 255u) == 255u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { give_up = 1; break; }
+                if (++spins > DuoCfg::kSpinLimit) { give_up = 2; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            misc[6] = give_up;
+        }
+        __syncthreads();
+        if (misc[6] != 0) {
+            if (tid == 0) { duo_store_release(flags + 32, DuoCfg::kAbort); if (misc[6] == 2) atomicMax(status, kErrStream); }
+            return;
+        }
+        const uint32_t* const rec = ring_g + (size_t)(k % DuoCfg::SLOTS) * DuoCfg::REC_WORDS;
+        const uint32_t sp = __builtin_nontemporal_load(rec + 0), op = __builtin_nontemporal_load(rec + 1), ng = __builtin_nontemporal_load(rec + 2);
+        const uint32_t next_op = __builtin_nontemporal_load(rec + 3), flg = __builtin_nontemporal_load(rec + 4), next_sp = __builtin_nontemporal_load(rec + 5);
+        if (flg & DuoCfg::kError) return;                                              // (the PARSE workgroup has reported it)
+        // this thread's pair words and group output offsets: on their way from L2 while the stream is staged
+        uint32_t pw_g[2] = {0, 0}, go_g[2] = {0, 0};
+#pragma unroll
+        for (uint32_t rep = 0; rep < 2; ++rep) {
+            const uint32_t gi = tid + rep * C::T;
+            if (gi < ng * 4u) { pw_g[rep] = rec[DuoCfg::HDR + gi]; go_g[rep] = rec[DuoCfg::HDR + 4u * C::MAXG + (gi >> 2)]; }
+        }
+        const bool last_chunk = (flg & DuoCfg::kLast) != 0u;
+        const uint32_t image_len = next_op - op;
+        const uint32_t avail = in_len - sp;
+        // ---------------- the chunk's stream to LDS (prefetched a chunk ago when the header was there in time), the record words cleared
+        if (pre_sp != sp) prefetch(sp);
+        if (tid < C::SWORDS) {
+            uint4 w = pre;
+            const uint32_t lim = avail < C::S + C::SPAD ? avail : C::S + C::SPAD, o = tid << 4;
+            if (o < lim && o + 16u > lim) {
+                uint32_t b[4] = {0, 0, 0, 0};
+                for (uint32_t q = 0; o + q < lim; ++q) b[q >> 2] |= (uint32_t)in[sp + o + q] << (8u * (q & 3u));
+                w = make_uint4(b[0], b[1], b[2], b[3]);
+            }
+            *reinterpret_cast<uint4*>(sbuf + (tid << 4)) = w;
+        }
+        for (uint32_t w = tid; w < (C::OUTC + 16) / 4; w += C::T) *reinterpret_cast<uint4*>(recw + 4u * w) = make_uint4(0, 0, 0, 0);
+        if (!last_chunk) prefetch(next_sp);
+        __syncthreads();
+
+        // ---------------- P5 (tsq_dec_sym.cuh): symbols -> bytes
+        const uint32_t lead = ring_op & 3u;
+        const uint32_t a0 = ring_op - lead;
+        if (tid == 0 && lead) recw[0] = 0x40000000u | (DuoCopyLds::ring + a0);
+        uint32_t bad = 0;
+#pragma unroll
+        for (uint32_t rep = 0; rep < 2; ++rep) {
+            const uint32_t gi = tid + rep * C::T;
+            if (gi >= ng * 4u) break;
+            const uint32_t pw = pw_g[rep];
+            uint32_t p = pw & 0x1FFFu, j = go_g[rep] + ((pw >> 13) & 0x3FFFu);
+            const uint32_t origin = j;
+            uint32_t sb = 0;
+            if (j < size) { if (p >= avail) bad = 1; sb = sbuf[p]; p++; }
+#pragma unroll
+            for (uint32_t sidx = 0; sidx < 2; ++sidx) {
+                if (j < size && !bad) {
+                    const uint32_t nib = sidx == 0 ? sb >> 4 : sb & 15u;
+                    const uint32_t lit = (pw >> (31u - sidx)) & 1u;
+                    const uint32_t room = size - j;
+                    const uint32_t ij = j - op + lead;
+                    if (lit) {
+                        const uint32_t len = nib + 1u, take = len < room ? len : room;
+                        if (p + take > avail) bad = 1;
+                        else recw[ij] = 0x40000000u | ((DuoCopyLds::sbuf + p - ij) & 0xFFFFFFu);
+                        p += len; j += take;
+                    } else {
+                        if (p + 2u > avail) bad = 1;
+                        const uint32_t off = (uint32_t)sbuf[p] | ((uint32_t)sbuf[p + 1] << 8);
+                        p += 2;
+                        const uint32_t len = sym_out_len(nib, 0, ext);
+                        const uint32_t take = len < room ? len : room;
+                        if (off > origin || take > off) bad = 1;
+                        if (!bad) {
+                            const uint32_t a = origin - off;
+                            const uint32_t n_hist = a >= op ? 0u : (op - a < take ? op - a : take);
+                            if (n_hist) {
+                                uint32_t x0 = a0 + C::R - ((op - a) - lead);
+                                x0 -= x0 >= C::R ? C::R : 0u;
+                                recw[ij] = 0x40000000u | ((DuoCopyLds::ring + x0 - ij) & 0xFFFFFFu);
+                                if (x0 + n_hist > C::R) { const uint32_t n1 = C::R - x0; recw[ij + n1] = 0x40000000u | ((DuoCopyLds::ring - (ij + n1)) & 0xFFFFFFu); }
+                            }
+                            if (n_hist < take) recw[ij + n_hist] = 0xC0000000u | ((a - j) & 0xFFFFFFu);
+                        }
+                        j += take;
+                    }
+                }
+            }
+        }
+        if (bad) misc[4] = kErrStream;
+        __syncthreads();
+        k++;
+        if (misc[4] != 0) {
+            if (tid == 0) { atomicMax(status, (int32_t)misc[4]); duo_store_release(flags + 32, DuoCfg::kAbort); }
+            return;
+        }
+        if (tid == 0) duo_store_release(flags + 32, k);                              // the record's slot is free
+        typedef __attribute__((address_space(3))) uint16_t lds_u16;
+        lds_u16* const le = (lds_u16*)(lds + DuoCopyLds::ent);
+        lds_u16* const wl = (lds_u16*)(lds + DuoCopyLds::plist) + 768u * wid;
+        const uint32_t own = 12u * tid;
+        uint32_t r[12];
+        {
+            const uint4 q0 = *reinterpret_cast<const uint4*>(recw + own), q1 = *reinterpret_cast<const uint4*>(recw + own + 4u),
+                        q2 = *reinterpret_cast<const uint4*>(recw + own + 8u);
+            r[0] = q0.x; r[1] = q0.y; r[2] = q0.z; r[3] = q0.w; r[4] = q1.x; r[5] = q1.y; r[6] = q1.z; r[7] = q1.w; r[8] = q2.x; r[9] = q2.y; r[10] = q2.z; r[11] = q2.w;
+#pragma unroll
+            for (uint32_t q = 1; q < 12; ++q) r[q] = r[q] ? r[q] : r[q - 1];
+            const uint32_t key = wave_scan_max(r[11] ? lane + 1u : 0u);
+            const uint32_t from = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x138, 0xF, 0xF, false);
+            uint32_t carry = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((from ? from - 1u : 0u) << 2), (int)r[11]);
+            carry = from ? carry : 0u;
+            const uint32_t upto = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((key ? key - 1u : 0u) << 2), (int)r[11]);
+            if (lane == 63) wsum[wid] = key ? upto : 0u;
+            __syncthreads();
+            {
+                const uint32_t ws = lane < 16u ? wsum[lane] : 0u;
+                const uint64_t m = __ballot(ws != 0u && lane < wid);
+                const uint32_t prev = m ? (uint32_t)__builtin_amdgcn_readlane((int)ws, 63 - __builtin_clzll(m)) : 0u;
+                carry = carry ? carry : prev;
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < 12; ++q) r[q] = r[q] ? r[q] : carry;
+        }
+        const bool live = own < lead + image_len;
+        uint32_t pend = 0;
+        if (live) {
+            uint32_t v[12], by[12];
+#pragma unroll
+            for (uint32_t q = 0; q < 12; ++q) {
+                v[q] = own + q + (uint32_t)((int32_t)(r[q] << 8) >> 8);
+                pend |= (r[q] >> 31) << q;
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < 12; ++q) by[q] = lds[(r[q] >> 31) ? 0u : v[q]];
+#pragma unroll
+            for (uint32_t q = 0; q < 12; ++q) v[q] = (r[q] >> 31) ? v[q] : (0x8000u | by[q]);
+#pragma unroll
+            for (uint32_t w = 0; w < 3; ++w)
+                *reinterpret_cast<uint2*>(lds + DuoCopyLds::ent + 2u * own + 8u * w) = make_uint2(v[4 * w] | (v[4 * w + 1] << 16), v[4 * w + 2] | (v[4 * w + 3] << 16));
+        }
+        uint32_t n_wait;
+        {
+            const uint32_t cnt = (uint32_t)__builtin_popcount(pend);
+            const uint32_t incl = wave_scan_add(cnt);
+            n_wait = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            uint32_t at = incl - cnt;
+#pragma unroll
+            for (uint32_t q = 0; q < 12; ++q) {
+                if ((pend >> q) & 1u) wl[at] = (uint16_t)(own + q);
+                at += (pend >> q) & 1u;
+            }
+        }
+        __syncthreads();
+        {
+            const uint32_t spare = C::OUTC + wid;
+            if (lane == 0) le[spare] = 0x8000u;
+            const uint32_t passes = (n_wait + 63u) >> 6;
+            const uint32_t padded = passes <= 2u ? 2u : passes <= 4u ? 4u : passes <= 6u ? 6u : passes <= 8u ? 8u : 12u;
+            if (passes) for (uint32_t it = n_wait + lane; it < padded * 64u; it += 64u) wl[it] = (uint16_t)spare;
+            auto jump = [&](auto passes_c) {
+                constexpr uint32_t P = decltype(passes_c)::value;
+                uint32_t q[P], ptr[P];
+#pragma unroll
+                for (uint32_t ps = 0; ps < P; ++ps) q[ps] = wl[ps * 64u + lane];
+#pragma unroll
+                for (uint32_t ps = 0; ps < P; ++ps) ptr[ps] = __hip_atomic_load(&le[q[ps]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (;;) {
+                    uint32_t e[P], open = 0;
+#pragma unroll
+                    for (uint32_t ps = 0; ps < P; ++ps) e[ps] = __hip_atomic_load(&le[(ptr[ps] & 0x8000u) ? q[ps] : ptr[ps]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                    for (uint32_t ps = 0; ps < P; ++ps) {
+                        __hip_atomic_store(&le[q[ps]], (uint16_t)e[ps], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        ptr[ps] = e[ps];
+                        open |= (e[ps] & 0x8000u) ^ 0x8000u;
+                    }
+                    if (__ballot(open != 0u) == 0ull) break;
+                }
+            };
+            if (passes == 0u) {}
+            else if (passes <= 2u) jump(std::integral_constant<uint32_t, 2>{});
+            else if (passes <= 4u) jump(std::integral_constant<uint32_t, 4>{});
+            else if (passes <= 6u) jump(std::integral_constant<uint32_t, 6>{});
+            else if (passes <= 8u) jump(std::integral_constant<uint32_t, 8>{});
+            else jump(std::integral_constant<uint32_t, 12>{});
+        }
+        __syncthreads();
+        if (live) {
+            const uint2 e0 = *reinterpret_cast<const uint2*>(lds + DuoCopyLds::ent + 2u * own), e1 = *reinterpret_cast<const uint2*>(lds + DuoCopyLds::ent + 2u * own + 8u),
+                        e2 = *reinterpret_cast<const uint2*>(lds + DuoCopyLds::ent + 2u * own + 16u);
+            const uint32_t ev[6] = {e0.x, e0.y, e1.x, e1.y, e2.x, e2.y};
+#pragma unroll
+            for (uint32_t w = 0; w < 3; ++w) {
+                uint32_t x = a0 + own + 4u * w; x -= x >= C::R ? C::R : 0u;
+                const uint32_t lo = ev[2 * w], hi = ev[2 * w + 1];
+                *reinterpret_cast<uint32_t*>(ring + x) = (lo & 0xFFu) | ((lo >> 8) & 0xFF00u) | ((hi & 0xFFu) << 16) | ((hi >> 16) << 24);
+            }
+        }
+        prev_op = op; prev_len = image_len; prev_ring = ring_op;
+        ring_op += image_len; ring_op -= ring_op >= C::R ? C::R : 0u;
+        __syncthreads();                                                               // the image is complete in the ring
+        if (last_chunk) break;
+    }
+    flush_image();
+}
+
+__global__ __launch_bounds__(1024) void dec_duo_kernel(const uint8_t* __restrict__ container, const FrameInfo* __restrict__ frames, uint32_t n_blocks,
+                                                       uint8_t* __restrict__ outbuf, int32_t* __restrict__ status,
+                                                       uint32_t* __restrict__ ring_g, uint32_t* __restrict__ flags_g)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t w = blockIdx.x, xcd = w & 7u, slot = w >> 3;
+    const uint32_t role = slot & 1u, b = (slot >> 1) * 8u + xcd;
+    if (b >= n_blocks) return;
+    const FrameInfo f = frames[b];
+    // (the frame descriptor may come from an untrusted container through tsqa_decode_blocks_async: bounds first)
+    if (f.stream_len < 3u || f.stream_len > kSlotSize || f.out_len > kBlockSize) {
+        if (threadIdx.x == 0) atomicMax(status, kErrStream);
+        return;
+    }
+    uint32_t* const ring_b = ring_g + (size_t)b * DuoCfg::SLOTS * DuoCfg::REC_WORDS;
+    uint32_t* const flags = flags_g + (size_t)b * DuoCfg::FLAG_STRIDE;
+    if (role == 0) duo_parse(container + f.stream_at, f.stream_len, f.out_len, f.ext, ring_b, flags, status, lds);
+    else duo_copy(container + f.stream_at, f.stream_len, f.out_len, f.ext, outbuf + f.out_at, ring_b, flags, status, lds);
+}
+
+}  // namespace tsq

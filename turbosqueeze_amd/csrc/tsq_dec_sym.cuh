@@ -121,8 +121,18 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
     // [4] error, [5] exit offset of the chain, [9], [10] instrumented builds only
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
-    if (*status != 0) return;
+    // Another block may have reported an error: leave, but all together (thread 0 reads the word, the workgroup branches on its copy
+    // in LDS -- a per-thread read could split the workgroup while other blocks are still writing the word).
+    if (tid == 0) misc[11] = (uint32_t)*status;
+    __syncthreads();
+    if (misc[11] != 0u) return;
     const FrameInfo f = frames[blockIdx.x];
+    // The descriptor may come straight from an untrusted container (tsqa_decode_blocks_async): a stream shorter than its 3-byte
+    // header, longer than a block slot, or an output longer than a block is refused before anything is read through it.
+    if (f.stream_len < 3u || f.stream_len > kSlotSize || f.out_len > kBlockSize) {
+        if (tid == 0) atomicMax(status, kErrStream);
+        return;
+    }
     const uint8_t* const in = container + f.stream_at;
     uint8_t* const out = outbuf + f.out_at;
     const uint32_t in_len = f.stream_len, size = f.out_len, ext = f.ext;

@@ -22,6 +22,9 @@ struct tsqa_ctx {
     tsq::FrameInfo* frames = nullptr;  // n_blocks frame descriptors (decode)
     uint16_t* tables = nullptr;        // n_blocks x 2^17 u16 position tables of the encoders
     size_t cap_blocks = 0, cap_tables = 0;
+    uint32_t* duo_ring = nullptr;      // two-workgroup decoder: chunk records handed from the PARSE to the COPY workgroup of a block
+    uint32_t* duo_flags = nullptr;     // and their progress counters
+    size_t cap_duo = 0;
     uint64_t* d_size = nullptr;        // result words of the synchronous entry points
     int32_t* d_status = nullptr;
     int enc_variant = 0, dec_variant = 0;
@@ -38,6 +41,7 @@ struct tsqa_ctx {
 
     void set_error(const char* fmt, ...) __attribute__((format(printf, 2, 3)));
     int reserve(size_t n_blocks, bool want_tables);
+    int reserve_duo(size_t n_blocks);
     // `readable` >= n: bytes of d_in that may be read (look-ahead halo); zeros are seen beyond it
     int launch_encode(const void* d_in, size_t n, size_t readable, uint32_t ext, int32_t* status, hipStream_t s);
     // general form: block b at d_in + b * stride, streams to slots_out[b * TSQ_OUTPUT_SZ], sizes to sizes_out[b]

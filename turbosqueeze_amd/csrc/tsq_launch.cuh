@@ -13,6 +13,7 @@
 #include "tsq_internal.h"
 #include "tsq_serial.cuh"
 #include "tsq_dec_sym.cuh"
+#include "tsq_dec_duo.cuh"
 #include "tsq_enc_stage.cuh"
 #ifdef TSQ_AB_VARIANTS
 #include "ab/tsq_dec_ring.cuh"
@@ -117,6 +118,20 @@ inline int launch_decode_kernels(tsqa_ctx* c, const uint8_t* container, const Fr
 #else
     if (v == 8 || v == 9) { c->set_error("kernel variant %d lives in the A/B library only (make ab)", v); return TSQA_ERR_ARG; }
 #endif
+    // Few blocks (at most half as many as CUs: every GPU of a multi-GPU job on enwik9): two workgroups per block, one for each of
+    // the block's two serial chains (tsq_dec_duo.cuh).
+    if (v == 3 || (v == 0 && 2u * n_blocks <= (uint32_t)c->n_cus)) {
+        static std::atomic<uint64_t> duo_devices{0};
+        const void* const fns[1] = {reinterpret_cast<const void*>(dec_duo_kernel)};
+        const uint32_t lds_bytes = DuoCopyLds::total > SymLds::total ? DuoCopyLds::total : SymLds::total;
+        const uint32_t bytes[1] = {lds_bytes};
+        if (int rc = raise_lds_limit(c, duo_devices, fns, bytes)) return rc;
+        if (int rc = c->reserve_duo(n_blocks)) return rc;
+        if (hipMemsetAsync(c->duo_flags, 0, (size_t)n_blocks * DuoCfg::FLAG_STRIDE * sizeof(uint32_t), s) != hipSuccess) { c->set_error("hipMemsetAsync failed"); return TSQA_ERR_HIP; }
+        const uint32_t grid = 16u * ((n_blocks + 7u) / 8u);
+        hipLaunchKernelGGL(dec_duo_kernel, dim3(grid), dim3(SymCfg::T), lds_bytes, s, container, frames, n_blocks, out, status, c->duo_ring, c->duo_flags);
+        return 0;
+    }
     // one workgroup per block at any block count: with more blocks than CUs the blocks simply queue (the decoder needs its 150 KB
     // of LDS; the two-per-CU layout of the byte-granular decoder was 1.85x slower per byte, tools/config5_sweep.py)
     hipLaunchKernelGGL(dec_sym_kernel, dim3(n_blocks), dim3(SymCfg::T), SymLds::total, s, container, frames, out, status);

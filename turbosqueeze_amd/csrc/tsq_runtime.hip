@@ -78,6 +78,7 @@ extern "C" void tsqa_destroy(tsqa_ctx* c)
     for (hipEvent_t e : c->prof_pool) if (e) (void)hipEventDestroy(e);
     (void)hipFree(c->slots); (void)hipFree(c->tables); (void)hipFree(c->sizes); (void)hipFree(c->frame_at);
     (void)hipFree(c->frames); (void)hipFree(c->d_size); (void)hipFree(c->d_status);
+    (void)hipFree(c->duo_ring); (void)hipFree(c->duo_flags);
     delete c;
 }
 
@@ -108,6 +109,20 @@ int tsqa_ctx::reserve(size_t n_blocks, bool want_tables)
         TSQ_HIP(this, hipMalloc(&tables, n_blocks * (size_t)kHashEntries * sizeof(uint16_t)));
         cap_tables = n_blocks;
     }
+    return TSQA_OK;
+}
+
+// Scratch of the two-workgroup decoder (tsq_dec_duo.cuh): four chunk records and two counters per block.
+int tsqa_ctx::reserve_duo(size_t n_blocks)
+{
+    (void)hipSetDevice(device);
+    if (n_blocks <= cap_duo) return TSQA_OK;
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(duo_ring); (void)hipFree(duo_flags);
+    duo_ring = nullptr; duo_flags = nullptr; cap_duo = 0;
+    TSQ_HIP(this, hipMalloc(&duo_ring, n_blocks * (size_t)DuoCfg::SLOTS * DuoCfg::REC_WORDS * sizeof(uint32_t)));
+    TSQ_HIP(this, hipMalloc(&duo_flags, n_blocks * (size_t)DuoCfg::FLAG_STRIDE * sizeof(uint32_t)));
+    cap_duo = n_blocks;
     return TSQA_OK;
 }
 

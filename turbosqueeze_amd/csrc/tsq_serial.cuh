@@ -108,8 +108,12 @@ __global__ __launch_bounds__(64) void dec_serial_kernel(const uint8_t* __restric
                                                         int32_t* __restrict__ status)
 {
     const uint32_t b = blockIdx.x, lane = threadIdx.x;
-    if (*status != 0) return;
+    if (uniform((uint32_t)*status) != 0u) return;           // (one wavefront: the first lane's reading decides for all)
     const FrameInfo f = frames[b];
+    if (f.stream_len < 3u || f.stream_len > kSlotSize || f.out_len > kBlockSize) {       // untrusted descriptors: see dec_sym_kernel
+        if (lane == 0) atomicMax(status, kErrStream);
+        return;
+    }
     const uint8_t* in = container + f.stream_at;
     uint8_t* out = outbuf + f.out_at;
     const uint32_t in_len = f.stream_len, size = f.out_len, ext = f.ext;
