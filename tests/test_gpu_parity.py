@@ -357,6 +357,25 @@ def test_all_kernel_variants_agree(tsq, oracle):
     c.close()
 
 
+def test_encoder_handoffs_under_jitter(tsq, oracle):
+    """The staged encoder's wavefronts hand records to each other through LDS counters and rely on the LDS executing a wavefront's
+    operations in order (tsq_enc_stage.cuh: stage_publish).  The stress build delays every publication by a pseudo-random time that
+    differs from block to block: 96 copies of one block (and of a second, incompressible-in-parts one) in one launch run the
+    pipeline under 96 interleavings each; every stream must be the oracle's, both levels."""
+    assert os.path.exists(tsq.lib_path("jitter")), "run __graft_entry__.build() first"
+    c = tsq.DeviceCodec(0, ab="jitter")
+    B = 1 << 22
+    for seed, maker in ((41, tsq.synth.text), (42, tsq.synth.mix)):
+        one = maker(B, seed=seed)
+        host = np.tile(one, 96)
+        dev = to_dev(host)
+        for ext in (0, 1):
+            blob = to_bytes(c.compress(dev, ext))
+            want = oracle.compress(host, ext, threads=8)
+            assert blob == want, (seed, ext)
+    c.close()
+
+
 def test_sharded_blocks_api(tsq, oracle):
     """tsqa_encode_blocks_async / tsqa_decode_blocks_async / tsqa_frames_{to,from}_host_async through ShardedCodec:
     one job dealt over 3 'ranks' (three contexts on this GPU, one after the other), frames gathered in ONE host

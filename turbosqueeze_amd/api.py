@@ -26,16 +26,18 @@ class TsqError(RuntimeError):
         super().__init__(f"turbosqueeze_amd error {code} ({ERRORS.get(code, '?')}) {detail}".strip())
 
 
-def lib_path(ab: bool = False) -> str:
-    """The product library, or (ab=True) the A/B library that also carries the superseded kernel
-    generations (variants 2-5; `make -C turbosqueeze_amd/csrc ab`)."""
+def lib_path(ab=False) -> str:
+    """The product library; ab=True: the A/B library that also carries the superseded kernel generations
+    (`make -C turbosqueeze_amd/csrc ab`); ab="jitter": the hand-off stress build of the encoder (`make jitter`)."""
+    if isinstance(ab, str):
+        return os.path.join(HERE, f"libturbosqueeze_amd_{ab}.so")
     return os.path.join(HERE, "libturbosqueeze_amd_ab.so" if ab else "libturbosqueeze_amd.so")
 
 
 def build_native(force: bool = False) -> None:
     """Compile every HIP source for gfx950 into turbosqueeze_amd/*.so (in-tree)."""
     csrc = os.path.join(HERE, "csrc")
-    args = ["make", "-C", csrc, "all", "ab"]
+    args = ["make", "-C", csrc, "all", "ab", "jitter"]
     if force:
         subprocess.check_call(["make", "-C", csrc, "clean"], stdout=subprocess.DEVNULL)
     subprocess.check_call(args, stdout=subprocess.DEVNULL)
@@ -44,7 +46,7 @@ def build_native(force: bool = False) -> None:
 _libs = {}
 
 
-def lib(ab: bool = False) -> C.CDLL:
+def lib(ab=False) -> C.CDLL:
     """Load the native library.  Fails loudly when it is missing: there is no other path."""
     if ab in _libs:
         return _libs[ab]
@@ -135,7 +137,7 @@ def container_bound(n: int) -> int:
 class DeviceCodec:
     """Device-resident compress/decompress over torch uint8 CUDA tensors (tsqa_* C ABI)."""
 
-    def __init__(self, device: int = -1, ab: bool = False):
+    def __init__(self, device: int = -1, ab=False):
         import torch
         if not torch.cuda.is_available():
             raise TsqError(1, "torch sees no GPU")

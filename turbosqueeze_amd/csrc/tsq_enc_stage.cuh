@@ -92,6 +92,22 @@ enum : uint32_t { kCtlEvHead = 10, kCtlEvTail = 11, kCtlReplies = 12, kCtlReplyV
 #define TSQ_BEGIN() do {} while (0)
 #endif
 
+// Hand-off stress (-DTSQ_JITTER, `make jitter`; tests/test_gpu_parity.py::test_encoder_handoffs_under_jitter): every publication
+// and every tile of every stage is delayed by a pseudo-random number of cycles that differs from block to block, so that one launch
+// over many copies of a block runs the pipeline under many different interleavings; the streams must not change.
+#ifdef TSQ_JITTER
+__device__ __forceinline__ void stage_jitter(uint32_t salt)
+{
+    uint32_t x = (blockIdx.x + 1u) * 2654435761u ^ (salt + (threadIdx.x >> 6) * 977u) * 40503u;
+    x ^= x >> 13; x *= 0x5bd1e995u; x ^= x >> 15;
+    x = uniform(x);
+    if ((x & 3u) == 0u) for (uint32_t q = (x >> 2) & 15u; q != 0u; --q) __builtin_amdgcn_s_sleep(3);
+}
+#define TSQ_JIT(salt) stage_jitter(salt)
+#else
+#define TSQ_JIT(salt) do {} while (0)
+#endif
+
 // Consuming a record: the counter is read first, the record's words after it.  The LDS executes the DS operations of a
 // wavefront in program order (see stage_publish), so only the compiler has to be kept from hoisting record loads above
 // the counter load: the barrier below is the acquire half of the handshake at compiler level.
@@ -149,6 +165,7 @@ __device__ __forceinline__ bool stage_spin_seen(lds_u32_t* ctl, uint32_t word, u
 #define TSQ_LDS_RELEASE() asm volatile("" ::: "memory")
 __device__ __forceinline__ void stage_publish(lds_u32_t* ctl, uint32_t word, uint32_t value, uint32_t lane)
 {
+    TSQ_JIT(value * 64u + word);
     TSQ_LDS_RELEASE();
     if (lane == 0) __hip_atomic_store(&ctl[word], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -630,6 +647,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
         asm volatile("v_writelane_b32 %0, %1, 2" : "+v"(hv) : "s"(b));
         asm volatile("v_writelane_b32 %0, %1, 3" : "+v"(hv) : "s"(c));
         if (lane < 4u) e[lane] = hv;
+        TSQ_JIT(ev_head * 64u + 40u);
         TSQ_LDS_RELEASE();
         ev_head++;
         __hip_atomic_store(&ctl[kCtlEvHead], ev_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -848,6 +866,7 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
         return queue + (head % StageCfg::Q) * StageCfg::ITEM_WORDS;
     };
     auto slot_publish = [&]() {
+        TSQ_JIT(head * 64u + 41u);
         TSQ_LDS_RELEASE();
         head++;
         __hip_atomic_store(&ctl[0], head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
