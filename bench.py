@@ -37,22 +37,26 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def pmc_traffic(kernel_substr: str):
-    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC summary of this same
-    command (tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes), corrected as
+def pmc_traffic(kernel_substr: str, fingerprint: str):
+    """HBM-side bytes per launch of a kernel from the rocprofv3 PMC summary of this same command
+    (tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes), corrected as
     MI355X_MICROARCH.md prescribes for gfx950: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
-    bench.py cannot read PMCs itself; returns (bytes, source) or (None, None)."""
+    bench.py cannot read PMCs itself (rocprofv3 wraps the process): it takes the newest stored summary ONLY IF that summary was
+    made from the kernel sources that are running now (same `kernel_fingerprint`); otherwise the field is null.
+    Returns (bytes, source) or (None, reason)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write.json")))
     if not files:
-        return None, None
+        return None, "no PMC summary under profiles/"
     try:
         d = json.load(open(files[-1]))
+        if d.get("kernel_fingerprint") != fingerprint:
+            return None, f"{os.path.relpath(files[-1], ROOT)} was made from other kernel sources ({d.get('kernel_fingerprint')} != {fingerprint})"
         f = next(v["per_dispatch"] for k, v in d["fetch"].items() if kernel_substr in k)
         w = next(v["per_dispatch"] for k, v in d["write"].items() if kernel_substr in k)
         return int((2 * f + w) * 1024), os.path.relpath(files[-1], ROOT)
-    except Exception:
-        return None, None
+    except Exception as e:
+        return None, f"unreadable PMC summary: {e}"
 
 
 def cpu_baseline(sample_bytes: int, ext: int, reps: int = 5):
@@ -201,8 +205,9 @@ def main():
     ap.add_argument("--ext", type=int, default=0, help="0 = --no-ext fast level (the published enwik9 row), 1 = with extensions")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-oracle-check", action="store_true", help="N = 1: skip the comparison of the timed job's container with the CPU oracle (after the timed region)")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the extra weak-scaling measurement")
-    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = production, 1 = serial baseline, 2-5 = A/B library)")
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = production, 1 = serial baselines, 5 = round 2's encoder from the A/B library)")
     args = ap.parse_args()
 
     import numpy as np
@@ -223,14 +228,13 @@ def main():
 
     n = args.size
     nb = (n + tsq.BLOCK_SZ - 1) // tsq.BLOCK_SZ
-    codec = tsq.DeviceCodec(local_rank, ab=2 <= args.variant <= 5)
-    codec.set_variant(args.variant, args.variant)
+    codec = tsq.DeviceCodec(local_rank, ab=args.variant == 5)
+    codec.set_variant(args.variant, args.variant if args.variant in (0, 1) else 0)
 
-    def single_gpu_job(seed, steps, warmup):
-        """The N=1 step on this rank's own job.  -> (dt, comp_bytes, enc/dec kernel ms+launches, call ms)"""
+    def single_gpu_job(seed, steps, warmup, check_oracle=False):
+        """The N=1 step on this rank's own job.  -> (dt, comp_bytes, enc/dec kernel ms+launches, call ms, container == oracle's)"""
         host = tsq.synth.text(n, seed=seed)
         src = torch.from_numpy(host).to(dev)
-        del host
         container = torch.empty(tsq.container_bound(n), dtype=torch.uint8, device=dev)
         back = torch.empty(n, dtype=torch.uint8, device=dev)
 
@@ -257,18 +261,28 @@ def main():
         torch.cuda.synchronize()
         comp_bytes, status = codec.last_size_status()
         assert status == 0
-        del src, container, back
+        oracle_equal = None
+        if check_oracle:
+            # ... and, outside the timed region, the timed job's container byte for byte against the CPU oracle (the checker)
+            from oracle import pyoracle
+            want = pyoracle.Oracle().compress(host, args.ext, threads=min(32, os.cpu_count() or 1))
+            got = container[:comp_bytes].cpu().numpy()
+            oracle_equal = bool(len(want) == comp_bytes and got.tobytes() == want)
+            assert oracle_equal, "the timed job's container differs from the oracle's"
+        del src, container, back, host
         torch.cuda.empty_cache()
-        return dt, comp_bytes, kern, calls
+        return dt, comp_bytes, kern, calls, oracle_equal
 
     line = None
     if world == 1:
-        dt, comp_bytes, (enc_ms, enc_n, dec_ms, dec_n), (cmp_ms, cmp_n, dcm_ms, dcm_n) = single_gpu_job(1, args.steps, args.warmup)
+        dt, comp_bytes, (enc_ms, enc_n, dec_ms, dec_n), (cmp_ms, cmp_n, dcm_ms, dcm_n), oracle_equal = single_gpu_job(1, args.steps, args.warmup, check_oracle=not args.no_oracle_check)
         peak_best, peak_med = codec.measure_copy(4 << 30, 7)
+        probe_shape = codec.last_error()
         alg, enc_e, dec_e, dom, enc_avg, dec_avg = roofline_entries(n, comp_bytes, enc_ms, enc_n, dec_ms, dec_n, peak_best)
-        traffic, traffic_src = (None, None)
+        traffic, traffic_src = (None, "PMC summaries are collected for the default job only")
+        fingerprint = tsq.source_fingerprint()
         if args.variant == 0 and args.ext == 0 and n == 1_000_000_000:
-            traffic, traffic_src = pmc_traffic("enc_" if dom[0] == "encode" else "dec_")
+            traffic, traffic_src = pmc_traffic("enc_" if dom[0] == "encode" else "dec_", fingerprint)
         cmp_avg = cmp_ms / max(cmp_n, 1) * 1e-3
         dcm_avg = dcm_ms / max(dcm_n, 1) * 1e-3
         line = {
@@ -279,13 +293,16 @@ def main():
             "config": {"workload": f"enwik9-shaped synthetic text, one {n} B job ({nb} blocks of 4 MiB), "
                                    f"{'with-extensions' if args.ext else '--no-ext'} level, device-resident, bit-exact round trip",
                        "job_bytes": n, "blocks": nb, "ext": args.ext, "ratio": round(comp_bytes / n, 5),
-                       "sharding": "1 GPU owns every block", "kernel_variant": args.variant},
+                       "sharding": "1 GPU owns every block", "kernel_variant": args.variant,
+                       "container_equals_oracle": oracle_equal, "kernel_fingerprint": fingerprint},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(dom[1], 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(dom[1] / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(dom[2] * 1e3, 4),
+                         # the north star's decode criterion: compressed bytes READ per second by the decode kernel / HBM peak
+                         "decode_read_only_frac": dec_e["read_only_frac"],
                          "peak_measured": round(peak_best, 1), "peak_measured_median": round(peak_med, 1),
                          "frac_of_measured": round(dom[1] / peak_best, 6) if peak_best else None,
-                         "peak_measured_by": "copy_probe_kernel, 4 GiB, bytes read + written, best grid of 8..64 workgroups per CU, best of 7"},
+                         "peak_measured_by": "copy_probe_kernel over 4 GiB, bytes read + written, best of 7; shape chosen by the probe: " + probe_shape},
             "roofline_encode": enc_e, "roofline_decode": dec_e,
             # uncompressed bytes / time of the whole call: encode kernel + container pack; frame walk + decode kernel
             "encode_GBps": round(n / cmp_avg / 1e9, 4) if cmp_avg > 0 else 0.0,
@@ -341,7 +358,7 @@ def main():
         weak = None
         if not args.no_weak:
             wsteps = min(args.steps, 3)
-            wdt, wcomp, _, _ = single_gpu_job(1 + rank, wsteps, 1)
+            wdt, wcomp, _, _, _ = single_gpu_job(1 + rank, wsteps, 1)
             weak = {"value": round(aggregate_value(world * n, wdt, wsteps), 4), "unit": "GB/s", "steps": wsteps,
                     "what": f"every rank compresses and decompresses its own {n} B job resident in its HBM (no gather)"}
         if rank == 0:

@@ -20,6 +20,10 @@ for name in ("fetch", "write"):
             k = r["Kernel_Name"].split("(")[0]
             agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
     out[name] = {k: {"sum": v[0], "dispatches": v[1], "per_dispatch": v[0] / max(v[1], 1)} for k, v in agg.items() if "tsq" in k}
+import sys
+sys.path.insert(0, ".")
+import turbosqueeze_amd
+out["kernel_fingerprint"] = turbosqueeze_amd.source_fingerprint()
 json.dump(out, open("$OUT/pmc_summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY

@@ -13,6 +13,7 @@ from .api import (  # noqa: F401
     container_bound,
     lib,
     lib_path,
+    source_fingerprint,
     tsq_compress_mt,
     tsq_decode,
     tsq_decompress_mt,

@@ -43,6 +43,20 @@ def build_native(force: bool = False) -> None:
     subprocess.check_call(args, stdout=subprocess.DEVNULL)
 
 
+def source_fingerprint() -> str:
+    """Hash of the kernel and host sources the native libraries are built from (csrc/*.cuh, *.hip, *.h, ab/*): what a stored
+    profile must carry to be attributed to the code that is running (bench.py: roofline.traffic)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(HERE, "csrc")
+    for fn in sorted(glob.glob(os.path.join(csrc, "*.cuh")) + glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) +
+                     glob.glob(os.path.join(csrc, "ab", "*.cuh"))):
+        h.update(os.path.basename(fn).encode())
+        h.update(open(fn, "rb").read())
+    return h.hexdigest()[:16]
+
+
 _libs = {}
 
 
@@ -166,6 +180,9 @@ class DeviceCodec:
 
     def _err(self, rc):
         return TsqError(rc, self.L.tsqa_last_error(self.h).decode())
+
+    def last_error(self) -> str:
+        return self.L.tsqa_last_error(self.h).decode()
 
     def set_variant(self, enc: int, dec: int) -> None:
         self.L.tsqa_set_kernel_variant(self.h, enc, dec)

@@ -391,13 +391,34 @@ extern "C" int tsqa_frames_from_host_async(tsqa_ctx* c, const void* host_contain
 }
 
 // ---- the second roofline denominator: what a plain device copy reaches on this GPU ----
-__global__ __launch_bounds__(256) void copy_probe_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t words)
+// MODE 0: grid-stride, four independent 16-byte loads in flight per lane; 1: the same with non-temporal loads and stores;
+// 2: one pass, every thread moves four words 256 apart (no loop: as many workgroups as the buffer needs).
+typedef uint32_t probe_u32x4 __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ __launch_bounds__(256) void copy_probe_kernel(const probe_u32x4* __restrict__ src, probe_u32x4* __restrict__ dst, size_t words)
 {
+    if (MODE == 2) {
+        const size_t i = (size_t)blockIdx.x * 1024u + threadIdx.x;
+        if (i + 768u < words) {
+            const probe_u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + 256), c = __builtin_nontemporal_load(src + i + 512),
+                                d = __builtin_nontemporal_load(src + i + 768);
+            __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + 256);
+            __builtin_nontemporal_store(c, dst + i + 512); __builtin_nontemporal_store(d, dst + i + 768);
+        } else for (size_t k = i; k < words && k < i + 1024u; k += 256u) dst[k] = src[k];
+        return;
+    }
     const size_t step = (size_t)gridDim.x * 256u;
     size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
-    for (; i + 3 * step < words; i += 4 * step) {               // four independent 16-byte loads in flight per lane
-        const uint4 a = src[i], b = src[i + step], c = src[i + 2 * step], d = src[i + 3 * step];
-        dst[i] = a; dst[i + step] = b; dst[i + 2 * step] = c; dst[i + 3 * step] = d;
+    for (; i + 3 * step < words; i += 4 * step) {
+        if (MODE == 1) {
+            const probe_u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + step), c = __builtin_nontemporal_load(src + i + 2 * step),
+                                d = __builtin_nontemporal_load(src + i + 3 * step);
+            __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + step);
+            __builtin_nontemporal_store(c, dst + i + 2 * step); __builtin_nontemporal_store(d, dst + i + 3 * step);
+        } else {
+            const probe_u32x4 a = src[i], b = src[i + step], c = src[i + 2 * step], d = src[i + 3 * step];
+            dst[i] = a; dst[i + step] = b; dst[i + 2 * step] = c; dst[i + 3 * step] = d;
+        }
     }
     for (; i < words; i += step) dst[i] = src[i];
 }
@@ -406,7 +427,7 @@ extern "C" int tsqa_measure_copy(tsqa_ctx* c, size_t bytes, int reps, double* be
 {
     if (!c || bytes < (size_t(1) << 20) || reps < 1 || reps > 64) return TSQA_ERR_ARG;
     (void)hipSetDevice(c->device);
-    uint4 *a = nullptr, *b = nullptr;
+    probe_u32x4 *a = nullptr, *b = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const size_t words = bytes / 16;
     int rc = TSQA_OK;
@@ -414,25 +435,33 @@ extern "C" int tsqa_measure_copy(tsqa_ctx* c, size_t bytes, int reps, double* be
     if (hipMalloc(&a, words * 16) != hipSuccess || hipMalloc(&b, words * 16) != hipSuccess ||
         hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess ||
         hipMemsetAsync(a, 0x5a, words * 16, c->stream) != hipSuccess) rc = TSQA_ERR_HIP;
-    // the grid that copies fastest is found first (8, 16, 32 or 64 workgroups of 256 per CU), then measured `reps` times
+    // the shape that copies fastest is found first -- grid-stride kernels with 8, 16, 32 or 64 workgroups of 256 per CU, with default
+    // and with non-temporal accesses, and the one-pass kernel -- then measured `reps` times
     uint32_t grid = (uint32_t)c->n_cus * 8u;
+    int mode = 0;
+    auto launch = [&](int m, uint32_t g) {
+        if (m == 0) hipLaunchKernelGGL(copy_probe_kernel<0>, dim3(g), dim3(256), 0, c->stream, a, b, words);
+        else if (m == 1) hipLaunchKernelGGL(copy_probe_kernel<1>, dim3(g), dim3(256), 0, c->stream, a, b, words);
+        else hipLaunchKernelGGL(copy_probe_kernel<2>, dim3((uint32_t)((words + 1023u) / 1024u)), dim3(256), 0, c->stream, a, b, words);
+    };
     {
         float best_ms = 1e30f;
-        for (uint32_t per_cu = 8; per_cu <= 64 && rc == TSQA_OK; per_cu *= 2) {
-            const uint32_t g = (uint32_t)c->n_cus * per_cu;
-            float ms = 1e30f;
-            for (int k = 0; k < 2; ++k) {
-                (void)hipEventRecord(e0, c->stream);
-                hipLaunchKernelGGL(copy_probe_kernel, dim3(g), dim3(256), 0, c->stream, a, b, words);
-                (void)hipEventRecord(e1, c->stream);
-                if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = TSQA_ERR_HIP; break; }
+        for (int m = 0; m < 3 && rc == TSQA_OK; ++m)
+            for (uint32_t per_cu = 8; per_cu <= (m == 2 ? 8u : 64u) && rc == TSQA_OK; per_cu *= 2) {
+                const uint32_t g = (uint32_t)c->n_cus * per_cu;
+                float ms = 1e30f;
+                for (int k = 0; k < 2; ++k) {
+                    (void)hipEventRecord(e0, c->stream);
+                    launch(m, g);
+                    (void)hipEventRecord(e1, c->stream);
+                    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = TSQA_ERR_HIP; break; }
+                }
+                if (ms < best_ms) { best_ms = ms; grid = g; mode = m; }
             }
-            if (ms < best_ms) { best_ms = ms; grid = g; }
-        }
     }
     for (int r = -1; r < reps && rc == TSQA_OK; ++r) {          // r == -1 warms up
         (void)hipEventRecord(e0, c->stream);
-        hipLaunchKernelGGL(copy_probe_kernel, dim3(grid), dim3(256), 0, c->stream, a, b, words);
+        launch(mode, grid);
         (void)hipEventRecord(e1, c->stream);
         float ms = 0;
         if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0) { rc = TSQA_ERR_HIP; break; }
@@ -442,6 +471,7 @@ extern "C" int tsqa_measure_copy(tsqa_ctx* c, size_t bytes, int reps, double* be
         for (int i = 1; i < reps; ++i) for (int j = i; j > 0 && rates[j] < rates[j - 1]; --j) { double t = rates[j]; rates[j] = rates[j - 1]; rates[j - 1] = t; }
         if (best_gbps) *best_gbps = rates[reps - 1];
         if (median_gbps) *median_gbps = rates[reps / 2];
+        c->set_error("copy probe: mode %d (0 grid-stride, 1 grid-stride non-temporal, 2 one pass non-temporal), %u workgroups", mode, mode == 2 ? (uint32_t)((words + 1023u) / 1024u) : grid);
     } else c->set_error("copy probe failed");
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
