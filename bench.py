@@ -331,18 +331,33 @@ def main():
         d_back = torch.empty(max(lay.shard_bytes, 1), dtype=torch.uint8, device=dev)
         size_seen = [0]
 
+        barrier_s = [0.0, 0.0]
+
         def step():
             size_seen[0] = sc.compress(d_shard)
+            t0 = time.perf_counter()
             dist.barrier()                                # every rank's frames are in the host container
+            t1 = time.perf_counter()
             sc.decompress(size_seen[0], d_back)
+            t2 = time.perf_counter()
             dist.barrier()                                # nobody overwrites the container while another still reads it
+            barrier_s[0] += t1 - t0
+            barrier_s[1] += time.perf_counter() - t2
 
         for _ in range(args.warmup):
             step()
         codec.profile(True)
+        for k in sc.seconds:
+            sc.seconds[k] = 0.0
+        barrier_s[0] = barrier_s[1] = 0.0
         dt = timed_steps(step, args.steps, 0, world, torch.cuda.synchronize, red_dev)
         enc_ms, enc_n, dec_ms, dec_n = codec.profile_read()
         codec.profile(False)
+        # where this rank's step went (wall ms per step; rank 0's view): encode = launch + wait for the kernel, size_gather = the
+        # all-gather of u32 sizes, place_d2h = frames to the host container, fetch_h2d_decode = frame walk + frames back + decode
+        breakdown = {k: round(v / args.steps * 1e3, 3) for k, v in sc.seconds.items()}
+        breakdown["barrier_after_place"] = round(barrier_s[0] / args.steps * 1e3, 3)
+        breakdown["barrier_after_decode"] = round(barrier_s[1] / args.steps * 1e3, 3)
         assert torch.equal(d_back[:lay.shard_bytes], expect), "round trip mismatch on rank %d" % rank
         comp_bytes = size_seen[0]
         # the host-gathered container is a well-formed .tsq file of the whole job
@@ -374,6 +389,7 @@ def main():
                            "sharding": f"block b -> rank b % {world}; one all-gather of the u32 sizes per step, frames DMA'd to one host container, barrier, owned frames back and decoded",
                            "kernel_variant": args.variant},
                 "slowest_rank_kernel_ms": {"encode": round(enc_avg * 1e3, 4), "decode": round(dec_avg * 1e3, 4)},
+                "rank0_step_breakdown_ms": breakdown,
                 "note": "one workgroup per 4 MiB block: the kernel time of a 239-block job is the per-block latency at any N (DESIGN.md section 6)",
             }
             if weak:

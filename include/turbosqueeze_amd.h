@@ -166,6 +166,28 @@ int tsqa_profile_read(tsqa_ctx *ctx, double *encode_ms, uint32_t *encode_launche
 int tsqa_profile_read_calls(tsqa_ctx *ctx, double *compress_ms, uint32_t *compress_calls,
                             double *decompress_ms, uint32_t *decompress_calls);
 
+/* One step of a block-sharded job on one rank (block b of the job belongs to rank b % world; what bench.py --gpus N and
+ * turbosqueeze_amd/sharding.py run).  The only exchange between ranks is the all-gather of the u32 stream sizes, made by the
+ * caller (torch.distributed / RCCL); everything else is here, one call per side:
+ *
+ * tsqa_frame_offsets / tsqa_walk_frames: host-only helpers (no device): the writer's prefix sum of 3 + size
+ *   (tsq_threads.cpp:226-239) and the reader's frame walk with validation (tsq_threads.cpp:513-524) over a container in host
+ *   memory.  TSQA_ERR_FORMAT on a malformed container.
+ * tsqa_sharded_place_async: after tsqa_encode_blocks_async and the all-gather, every owned stream (block b's at
+ *   d_slots + (b / world) * TSQ_OUTPUT_SZ) goes by DMA to its final place in ONE container in host memory, with its three
+ *   frame bytes; rank 0 also writes the 16-byte header.  *container_size is the same on every rank.
+ * tsqa_sharded_fetch_decode_async: walks the container, brings this rank's frames back to d_streams (k-th owned frame at
+ *   k * TSQ_OUTPUT_SZ) and decodes them back to back into d_out (k-th owned block at k * TSQ_BLOCK_SZ).
+ * Both replace the Python loops of round 2's sharding.py; the host container should be pinned / hipHostRegister'ed. */
+int tsqa_frame_offsets(const uint32_t *sizes, uint32_t n_blocks, uint64_t *frame_at, uint64_t *container_size);
+int tsqa_walk_frames(const void *container, size_t size, uint32_t cap_blocks, uint64_t *frame_at, uint32_t *sizes, uint32_t *ext,
+                     uint32_t *out_len, uint32_t *n_blocks, uint64_t *total);
+int tsqa_sharded_place_async(tsqa_ctx *ctx, const void *d_slots, const uint32_t *all_sizes, uint32_t n_blocks, uint64_t n_total,
+                             uint32_t rank, uint32_t world, uint32_t ext, void *host_container, size_t host_cap,
+                             uint64_t *container_size, void *hip_stream);
+int tsqa_sharded_fetch_decode_async(tsqa_ctx *ctx, const void *host_container, size_t container_size, uint32_t rank, uint32_t world,
+                                    void *d_streams, void *d_out, int32_t *d_status, uint64_t *total, void *hip_stream);
+
 /* The measured copy bandwidth of this GPU (bytes read + bytes written per second, GB/s = 1e9 B/s) by a plain
  * grid-stride 16-byte copy kernel over `bytes` of HBM: the second denominator beside the 8 TB/s specification when a
  * kernel is priced against the HBM roofline. */

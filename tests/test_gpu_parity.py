@@ -408,10 +408,8 @@ def test_sharded_blocks_api(tsq, oracle):
                 coders[r].blocks.sync()
                 all_sizes[np.asarray(lays[r].blocks)] = coders[r].blocks.sizes_tensor().cpu().numpy().astype(np.uint32)[:lays[r].n_local]
             frame_at, total = sharding.frame_offsets(all_sizes)
-            hc.array[:16] = np.frombuffer(b"TSQ1" + lays[0].nb.to_bytes(4, "little") + n.to_bytes(8, "little"), dtype=np.uint8)
-            for r in range(world):
-                own = np.asarray(lays[r].blocks)
-                coders[r].blocks.frames_to_host(np.ascontiguousarray(all_sizes[own]), np.ascontiguousarray(frame_at[own]), ext, hc)
+            for r in range(world):                       # (rank 0 writes the header; every rank its own frames: tsqa_sharded_place_async)
+                assert coders[r].blocks.place(all_sizes, lays[r], ext, hc) == total
                 coders[r].blocks.sync()
             assert total == len(want)
             assert bytes(hc.array[:total]) == want

@@ -66,23 +66,26 @@ WORKER = textwrap.dedent('''
                 self.sizes[k] = len(stream)
         def sizes_tensor(self):
             return self.sizes
-        def frames_to_host(self, sizes, frame_at, ext, hostc):
-            for k in range(len(sizes)):
-                frame = int(sizes[k]) | (0x800000 if ext else 0)
-                at = int(frame_at[k])
+        def place(self, all_sizes, lay, ext, hostc):
+            frame_at, total = sharding.frame_offsets(all_sizes)              # (the C helper the device path uses)
+            assert total <= hostc.size
+            if lay.rank == 0:
+                hostc.array[:16] = np.frombuffer(b"TSQ1" + lay.nb.to_bytes(4, "little") + lay.n_total.to_bytes(8, "little"), dtype=np.uint8)
+            for k, b in enumerate(lay.blocks):
+                frame = int(all_sizes[b]) | (0x800000 if ext else 0)
+                at = int(frame_at[b])
                 hostc.array[at:at + 3] = np.frombuffer(frame.to_bytes(3, "little"), dtype=np.uint8)
-                hostc.array[at + 3:at + 3 + int(sizes[k])] = self.slots[k * sharding.OUTPUT_SZ:k * sharding.OUTPUT_SZ + int(sizes[k])]
-        def frames_from_host(self, hostc, frame_at, sizes):
-            for k in range(len(sizes)):
-                at = int(frame_at[k]) + 3
-                self.slots[k * sharding.OUTPUT_SZ:k * sharding.OUTPUT_SZ + int(sizes[k])] = hostc.array[at:at + int(sizes[k])]
-        def decode(self, fr, n_local, d_out):
-            for k in range(n_local):
-                s0, ln = int(fr["stream_at"][k]), int(fr["stream_len"][k])
-                data, st = orc.decode_block(bytes(self.slots[s0:s0 + ln]), int(fr["ext"][k]))
-                assert st == 0 and len(data) == int(fr["out_len"][k])
-                o = int(fr["out_at"][k])
-                d_out[o:o + len(data)] = np.frombuffer(data, dtype=np.uint8)
+                hostc.array[at + 3:at + 3 + int(all_sizes[b])] = self.slots[k * sharding.OUTPUT_SZ:k * sharding.OUTPUT_SZ + int(all_sizes[b])]
+            return total
+        def fetch_decode(self, hostc, container_size, lay, d_out):
+            total, frame_at, sizes, ext, out_len = sharding.walk_frames(hostc.array, container_size)   # (the C helper)
+            assert len(sizes) == lay.nb
+            for k, b in enumerate(lay.blocks):
+                at = int(frame_at[b]) + 3
+                data, st = orc.decode_block(bytes(hostc.array[at:at + int(sizes[b])]), int(ext[b]))
+                assert st == 0 and len(data) == int(out_len[b])
+                d_out[k * sharding.BLOCK_SZ:k * sharding.BLOCK_SZ + len(data)] = np.frombuffer(data, dtype=np.uint8)
+            return total
         def sync(self):
             pass
 

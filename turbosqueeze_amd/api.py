@@ -128,6 +128,15 @@ def lib(ab=False) -> C.CDLL:
     L.tsqa_frames_to_host_async.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp]
     L.tsqa_frames_from_host_async.restype = C.c_int
     L.tsqa_frames_from_host_async.argtypes = [vp, vp, vp, vp, C.c_uint32, vp, vp]
+    u32p, u64p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    L.tsqa_frame_offsets.restype = C.c_int
+    L.tsqa_frame_offsets.argtypes = [vp, C.c_uint32, vp, u64p]
+    L.tsqa_walk_frames.restype = C.c_int
+    L.tsqa_walk_frames.argtypes = [vp, C.c_size_t, C.c_uint32, vp, vp, vp, vp, u32p, u64p]
+    L.tsqa_sharded_place_async.restype = C.c_int
+    L.tsqa_sharded_place_async.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, u64p, vp]
+    L.tsqa_sharded_fetch_decode_async.restype = C.c_int
+    L.tsqa_sharded_fetch_decode_async.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp, vp, u64p, vp]
     L.tsqa_measure_copy.restype = C.c_int
     L.tsqa_measure_copy.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.tsqCompress.restype = None
@@ -238,6 +247,24 @@ class DeviceCodec:
                                                 self._stream())
         if rc:
             raise self._err(rc)
+
+    def sharded_place_async(self, d_slots, all_sizes, n_total: int, rank: int, world: int, ext: int, host_ptr: int, host_cap: int) -> int:
+        """all_sizes: contiguous numpy uint32, one entry per block of the job.  -> container size."""
+        total = C.c_uint64(0)
+        rc = self.L.tsqa_sharded_place_async(self.h, d_slots.data_ptr(), all_sizes.ctypes.data, len(all_sizes), n_total, rank, world, int(ext),
+                                             host_ptr, host_cap, C.byref(total), self._stream())
+        if rc:
+            raise self._err(rc)
+        return int(total.value)
+
+    def sharded_fetch_decode_async(self, host_ptr: int, container_size: int, rank: int, world: int, d_streams, d_out) -> int:
+        """-> the job's uncompressed size (from the container header)."""
+        total = C.c_uint64(0)
+        rc = self.L.tsqa_sharded_fetch_decode_async(self.h, host_ptr, container_size, rank, world, d_streams.data_ptr(), d_out.data_ptr(),
+                                                    self._status.data_ptr(), C.byref(total), self._stream())
+        if rc:
+            raise self._err(rc)
+        return int(total.value)
 
     def status(self) -> int:
         return int(self._status.item())

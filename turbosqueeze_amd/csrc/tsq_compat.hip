@@ -536,7 +536,7 @@ private:
             if (!stage_out && !touching) { touch.start(sink.mem, (size_t)total); touching = true; }
             (void)hipSetDevice(l.dev->device);
             hipStream_t s = l.dev->stream;
-            if (l.dev->reserve(bn, false) != TSQA_OK) { ok = false; break; }
+            if (l.dev->reserve(bn, false, false) != TSQA_OK) { ok = false; break; }
             if (hipMemcpyAsync(l.d_in, stage_in ? l.h_in : src.mem + at, cur, hipMemcpyHostToDevice, s) != hipSuccess) { ok = false; break; }
             if (hipMemcpyAsync(l.dev->frames, l.h_frames, bn * sizeof(FrameInfo), hipMemcpyHostToDevice, s) != hipSuccess) { ok = false; break; }
             if (hipMemsetAsync(l.dev->d_status, 0, sizeof(int32_t), s) != hipSuccess) { ok = false; break; }
@@ -703,7 +703,7 @@ extern "C" void tsqDecode(uint8_t* inputBlock, uint8_t* outputBlock, uint32_t* o
     Lane& l = bc.lane;
     (void)hipSetDevice(l.dev->device);
     hipStream_t s = l.dev->stream;
-    if (l.dev->reserve(1, false) != TSQA_OK) return;
+    if (l.dev->reserve(1, false, false) != TSQA_OK) return;
     memcpy(l.h_in, inputBlock, inputSize);
     FrameInfo& fi = l.h_frames[0];
     fi.stream_at = 0; fi.out_at = 0; fi.stream_len = inputSize; fi.ext = withExtensions ? 1u : 0u; fi.out_len = usize; fi.pad = 0;

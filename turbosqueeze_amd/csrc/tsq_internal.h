@@ -21,7 +21,8 @@ struct tsqa_ctx {
     uint64_t* frame_at = nullptr;      // n_blocks + 1 frame offsets in the container
     tsq::FrameInfo* frames = nullptr;  // n_blocks frame descriptors (decode)
     uint16_t* tables = nullptr;        // n_blocks x 2^17 u16 position tables of the encoders
-    size_t cap_blocks = 0, cap_tables = 0;
+    size_t cap_blocks = 0, cap_tables = 0, cap_slots = 0;
+    std::vector<tsq::FrameInfo> host_frames;   // frame descriptors built on the host (sharded fetch + decode)
     uint32_t* duo_ring = nullptr;      // two-workgroup decoder: chunk records handed from the PARSE to the COPY workgroup of a block
     uint32_t* duo_flags = nullptr;     // and their progress counters
     size_t cap_duo = 0;
@@ -40,7 +41,7 @@ struct tsqa_ctx {
     void prof_end(int kind, hipStream_t s);
 
     void set_error(const char* fmt, ...) __attribute__((format(printf, 2, 3)));
-    int reserve(size_t n_blocks, bool want_tables);
+    int reserve(size_t n_blocks, bool want_tables, bool want_slots = true);
     int reserve_duo(size_t n_blocks);
     // `readable` >= n: bytes of d_in that may be read (look-ahead halo); zeros are seen beyond it
     int launch_encode(const void* d_in, size_t n, size_t readable, uint32_t ext, int32_t* status, hipStream_t s);

@@ -89,19 +89,24 @@ extern "C" void tsqa_set_kernel_variant(tsqa_ctx* c, int ev, int dv) { if (c) { 
 // Scratch in HBM, grown on demand and kept: slots (TSQ_OUTPUT_SZ per block, the reference's
 // per-block output buffer, tsq_context.cpp:89-143), per-block sizes, frame offsets, frame
 // descriptors and one 256 KiB position table per block for the encoders (want_tables).
-int tsqa_ctx::reserve(size_t n_blocks, bool want_tables)
+int tsqa_ctx::reserve(size_t n_blocks, bool want_tables, bool want_slots)
 {
     (void)hipSetDevice(device);
     if (n_blocks > cap_blocks) {
         size_t nb = n_blocks;
         (void)hipStreamSynchronize(stream);
-        (void)hipFree(slots); (void)hipFree(sizes); (void)hipFree(frame_at); (void)hipFree(frames);
-        slots = nullptr; sizes = nullptr; frame_at = nullptr; frames = nullptr; cap_blocks = 0;
-        TSQ_HIP(this, hipMalloc(&slots, nb * (size_t)kSlotSize + 256));
+        (void)hipFree(sizes); (void)hipFree(frame_at); (void)hipFree(frames);
+        sizes = nullptr; frame_at = nullptr; frames = nullptr; cap_blocks = 0;
         TSQ_HIP(this, hipMalloc(&sizes, nb * sizeof(uint32_t)));
         TSQ_HIP(this, hipMalloc(&frame_at, (nb + 1) * sizeof(uint64_t)));
         TSQ_HIP(this, hipMalloc(&frames, nb * sizeof(FrameInfo)));
         cap_blocks = nb;
+    }
+    if (want_slots && n_blocks > cap_slots) {        // (callers that bring their own slots -- the sharded block API -- never pay for these)
+        (void)hipStreamSynchronize(stream);
+        (void)hipFree(slots); slots = nullptr; cap_slots = 0;
+        TSQ_HIP(this, hipMalloc(&slots, n_blocks * (size_t)kSlotSize + 256));
+        cap_slots = n_blocks;
     }
     if (want_tables && n_blocks > cap_tables) {
         (void)hipStreamSynchronize(stream);
@@ -148,7 +153,14 @@ extern "C" int tsqa_profile_enable(tsqa_ctx* c, int on)
     if (on && c->prof_pool.empty()) {
         c->prof_pool.resize((size_t)tsqa_ctx::kProfKinds * tsqa_ctx::kProfPairs * 2, nullptr);
         for (auto& e : c->prof_pool)
-            if (hipEventCreate(&e) != hipSuccess) { c->set_error("hipEventCreate failed"); return TSQA_ERR_HIP; }
+            if (hipEventCreate(&e) != hipSuccess) {
+                // all or nothing: a half-made pool would hand null events to hipEventRecord later
+                for (hipEvent_t made : c->prof_pool) if (made) (void)hipEventDestroy(made);
+                c->prof_pool.clear();
+                c->profiling = false;
+                c->set_error("hipEventCreate failed");
+                return TSQA_ERR_HIP;
+            }
     }
     c->profiling = on != 0;
     return TSQA_OK;
@@ -193,11 +205,11 @@ int tsqa_ctx::launch_encode_to(const void* d_in, size_t n, size_t readable, size
                                uint32_t* sizes_out, int32_t* status, hipStream_t s)
 {
     const uint32_t nb = (uint32_t)tsqa_block_count(n);
-    int rc = reserve(nb, true);
+    int rc = reserve(nb, true, false);                   // (the streams go to the caller's slots: the context's own are not needed here)
     if (rc) return rc;
     const bool timed = prof_begin(0, s);
     rc = launch_encode_kernels(this, static_cast<const uint8_t*>(d_in), n, readable, stride, ext, slots_out, sizes_out, status, s);
-    if (rc) return rc;
+    if (rc) { if (timed) prof_used[0]--; return rc; }     // (the pair's end event was never recorded: give the pair back)
     if (timed) prof_end(0, s);
     TSQ_HIP(this, hipGetLastError());
     return TSQA_OK;
@@ -226,7 +238,7 @@ int tsqa_ctx::launch_decode_frames(const void* d_streams, const FrameInfo* d_fra
 {
     const bool timed = prof_begin(1, s);
     int rc = launch_decode_kernels(this, static_cast<const uint8_t*>(d_streams), d_frames, n_blocks, static_cast<uint8_t*>(d_out), status, s);
-    if (rc) return rc;
+    if (rc) { if (timed) prof_used[1]--; return rc; }
     if (timed) prof_end(1, s);
     TSQ_HIP(this, hipGetLastError());
     return TSQA_OK;
@@ -250,7 +262,7 @@ extern "C" int tsqa_compress_device_async(tsqa_ctx* c, const void* d_in, size_t 
     TSQ_HIP(c, hipMemsetAsync(d_status, 0, sizeof(int32_t), s));
     const bool timed = c->prof_begin(2, s);
     int rc = c->launch_encode(d_in, n, n, ext, d_status, s);
-    if (rc) return rc;
+    if (rc) { if (timed) c->prof_used[2]--; return rc; }
     rc = c->launch_pack(n, ext, d_out, out_cap, d_out_size, d_status, s);
     if (timed) c->prof_end(2, s);
     return rc;
@@ -285,7 +297,7 @@ extern "C" int tsqa_decompress_device_async(tsqa_ctx* c, const void* d_in, size_
     if (!d_in || !d_out || !d_out_size || !d_status || n < 16 || n_blocks == 0) { c->set_error("decompress: bad argument"); return TSQA_ERR_ARG; }
     hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
     (void)hipSetDevice(c->device);
-    int rc = c->reserve(n_blocks, false);
+    int rc = c->reserve(n_blocks, false, false);
     if (rc) return rc;
     TSQ_HIP(c, hipMemsetAsync(d_status, 0, sizeof(int32_t), s));
     const bool timed = c->prof_begin(3, s);
@@ -388,6 +400,123 @@ extern "C" int tsqa_frames_from_host_async(tsqa_ctx* c, const void* host_contain
         TSQ_HIP(c, hipMemcpyAsync(static_cast<uint8_t*>(d_streams) + (size_t)b * kSlotSize, base + frame_at[b] + 3, sizes[b], hipMemcpyHostToDevice, s));
     }
     return TSQA_OK;
+}
+
+// ---- one step of a block-sharded job on this rank (block b of the job belongs to rank b % world) ----
+// Host-only helpers first (no device involved): the writer's frame offsets and the reader's frame walk
+// (tsq_threads.cpp:226-239,513-524) over a container in host memory.
+extern "C" int tsqa_frame_offsets(const uint32_t* sizes, uint32_t n_blocks, uint64_t* frame_at, uint64_t* container_size)
+{
+    if (!sizes || !frame_at || !container_size) return TSQA_ERR_ARG;
+    uint64_t at = 16;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        if (sizes[b] < 3 || sizes[b] > kSlotSize) return TSQA_ERR_ARG;
+        frame_at[b] = at;
+        at += 3ull + sizes[b];
+    }
+    *container_size = at;
+    return TSQA_OK;
+}
+
+extern "C" int tsqa_walk_frames(const void* container, size_t size, uint32_t cap_blocks, uint64_t* frame_at, uint32_t* sizes, uint32_t* ext,
+                                uint32_t* out_len, uint32_t* n_blocks, uint64_t* total)
+{
+    if (!container || !frame_at || !sizes || !ext || !out_len || !n_blocks || !total) return TSQA_ERR_ARG;
+    const uint8_t* p = static_cast<const uint8_t*>(container);
+    if (size < 16 || memcmp(p, "TSQ1", 4) != 0) return TSQA_ERR_FORMAT;                    // tsq_threads.cpp:732-752
+    uint32_t nb; uint64_t tot;
+    memcpy(&nb, p + 4, 4); memcpy(&tot, p + 8, 8);
+    if (nb == 0 || (size_t)nb > (size - 16) / 6 || nb > cap_blocks) return TSQA_ERR_FORMAT;  // tsq_threads.cpp:759-768
+    uint64_t at = 16, sum = 0;
+    for (uint32_t b = 0; b < nb; ++b) {
+        if (at + 6 > size) return TSQA_ERR_FORMAT;
+        const uint32_t frame = (uint32_t)p[at] | ((uint32_t)p[at + 1] << 8) | ((uint32_t)p[at + 2] << 16);
+        const uint32_t len = frame & 0x7FFFFFu;                                             // tsq_threads.cpp:513-517
+        if (len < 3 || len > kSlotSize || at + 3 + len > size) return TSQA_ERR_FORMAT;
+        const uint32_t usize = (uint32_t)p[at + 3] | ((uint32_t)p[at + 4] << 8) | ((uint32_t)p[at + 5] << 16);
+        if (usize > kBlockSize) return TSQA_ERR_FORMAT;
+        frame_at[b] = at; sizes[b] = len; ext[b] = frame >> 23; out_len[b] = usize;
+        sum += usize;
+        at += 3ull + len;
+    }
+    if (sum != tot) return TSQA_ERR_FORMAT;
+    *n_blocks = nb; *total = tot;
+    return TSQA_OK;
+}
+
+// After the encode of the owned blocks and the all-gather of every block's stream size: this rank's frames go to their final
+// place in ONE container in host memory (rank 0 also writes the 16-byte header).  The whole "gather" of the writer thread
+// (tsq_threads.cpp:192-275) is this prefix sum and one DMA per owned block.
+extern "C" int tsqa_sharded_place_async(tsqa_ctx* c, const void* d_slots, const uint32_t* all_sizes, uint32_t n_blocks, uint64_t n_total,
+                                        uint32_t rank, uint32_t world, uint32_t ext, void* host_container, size_t host_cap,
+                                        uint64_t* container_size, void* hip_stream)
+{
+    if (!c) return TSQA_ERR_ARG;
+    if (!d_slots || !all_sizes || !host_container || !container_size || world == 0 || rank >= world || n_blocks == 0) { c->set_error("sharded_place: bad argument"); return TSQA_ERR_ARG; }
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    (void)hipSetDevice(c->device);
+    uint8_t* base = static_cast<uint8_t*>(host_container);
+    uint64_t at = 16;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        const uint32_t sz = all_sizes[b];
+        if (sz < 3 || sz > kSlotSize) { c->set_error("sharded_place: block %u has size %u", b, sz); return TSQA_ERR_ARG; }
+        if (at + 3ull + sz > host_cap) { c->set_error("sharded_place: the host container is too small"); return TSQA_ERR_ARG; }
+        if (b % world == rank) {
+            const uint32_t frame = sz | (ext ? 0x800000u : 0u);                          // tsq_threads.cpp:218-219
+            uint8_t* p = base + at;
+            p[0] = (uint8_t)frame; p[1] = (uint8_t)(frame >> 8); p[2] = (uint8_t)(frame >> 16);
+            TSQ_HIP(c, hipMemcpyAsync(p + 3, static_cast<const uint8_t*>(d_slots) + (size_t)(b / world) * kSlotSize, sz, hipMemcpyDeviceToHost, s));
+        }
+        at += 3ull + sz;
+    }
+    if (rank == 0) {                                                                      // tsq_threads.cpp:333-335
+        memcpy(base, "TSQ1", 4); memcpy(base + 4, &n_blocks, 4); memcpy(base + 8, &n_total, 8);
+    }
+    *container_size = at;
+    return TSQA_OK;
+}
+
+// The reader's side: walk the container's frames (host memory), bring this rank's frames to d_streams (frame k of the rank at
+// k * TSQ_OUTPUT_SZ) and decode them back to back into d_out (block k of the rank at k * TSQ_BLOCK_SZ).
+extern "C" int tsqa_sharded_fetch_decode_async(tsqa_ctx* c, const void* host_container, size_t container_size, uint32_t rank, uint32_t world,
+                                               void* d_streams, void* d_out, int32_t* d_status, uint64_t* total, void* hip_stream)
+{
+    if (!c) return TSQA_ERR_ARG;
+    if (!host_container || !d_streams || !d_out || !d_status || !total || world == 0 || rank >= world) { c->set_error("sharded_fetch_decode: bad argument"); return TSQA_ERR_ARG; }
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    (void)hipSetDevice(c->device);
+    const uint8_t* p = static_cast<const uint8_t*>(host_container);
+    if (container_size < 16 || memcmp(p, "TSQ1", 4) != 0) { c->set_error("sharded_fetch_decode: bad magic"); return TSQA_ERR_FORMAT; }
+    uint32_t nb; uint64_t tot;
+    memcpy(&nb, p + 4, 4); memcpy(&tot, p + 8, 8);
+    if (nb == 0 || (size_t)nb > (container_size - 16) / 6) { c->set_error("sharded_fetch_decode: bad block count"); return TSQA_ERR_FORMAT; }
+    const uint32_t n_local = nb > rank ? (nb - rank + world - 1) / world : 0;
+    if (int rc = c->reserve(n_local ? n_local : 1, false, false)) return rc;
+    c->host_frames.resize(n_local ? n_local : 1);
+    uint64_t at = 16, sum = 0;
+    for (uint32_t b = 0; b < nb; ++b) {
+        if (at + 6 > container_size) { c->set_error("sharded_fetch_decode: truncated container"); return TSQA_ERR_FORMAT; }
+        const uint32_t frame = (uint32_t)p[at] | ((uint32_t)p[at + 1] << 8) | ((uint32_t)p[at + 2] << 16);
+        const uint32_t len = frame & 0x7FFFFFu;
+        if (len < 3 || len > kSlotSize || at + 3 + len > container_size) { c->set_error("sharded_fetch_decode: bad frame %u", b); return TSQA_ERR_FORMAT; }
+        const uint32_t usize = (uint32_t)p[at + 3] | ((uint32_t)p[at + 4] << 8) | ((uint32_t)p[at + 5] << 16);
+        if (usize > kBlockSize) { c->set_error("sharded_fetch_decode: bad block size in frame %u", b); return TSQA_ERR_FORMAT; }
+        if (b % world == rank) {
+            const uint32_t k = b / world;
+            TSQ_HIP(c, hipMemcpyAsync(static_cast<uint8_t*>(d_streams) + (size_t)k * kSlotSize, p + at + 3, len, hipMemcpyHostToDevice, s));
+            FrameInfo f;
+            f.stream_at = (uint64_t)k * kSlotSize; f.out_at = (uint64_t)k * kBlockSize; f.stream_len = len; f.ext = frame >> 23; f.out_len = usize; f.pad = 0;
+            c->host_frames[k] = f;
+        }
+        sum += usize;
+        at += 3ull + len;
+    }
+    if (sum != tot) { c->set_error("sharded_fetch_decode: block sizes do not add up"); return TSQA_ERR_FORMAT; }
+    *total = tot;
+    TSQ_HIP(c, hipMemsetAsync(d_status, 0, sizeof(int32_t), s));
+    if (n_local == 0) return TSQA_OK;
+    TSQ_HIP(c, hipMemcpyAsync(c->frames, c->host_frames.data(), (size_t)n_local * sizeof(FrameInfo), hipMemcpyHostToDevice, s));
+    return c->launch_decode_frames(d_streams, c->frames, n_local, d_out, d_status, s);
 }
 
 // ---- the second roofline denominator: what a plain device copy reaches on this GPU ----

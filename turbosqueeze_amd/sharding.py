@@ -143,45 +143,38 @@ class ShardLayout:
 
 def frame_offsets(all_sizes):
     """Container offset of every block's frame bytes: 16 + sum over earlier blocks of (3 + size)
-    (tsq_threads.cpp:226-239).  -> (uint64 array of nb offsets, container size)."""
+    (tsq_threads.cpp:226-239).  -> (uint64 array of nb offsets, container size).  (C: tsqa_frame_offsets.)"""
+    import ctypes as C
     import numpy as np
-    sizes = np.asarray(all_sizes, dtype=np.uint64)
-    ends = 16 + np.cumsum(sizes + 3, dtype=np.uint64)
-    at = np.concatenate([np.array([16], dtype=np.uint64), ends[:-1]]) if len(sizes) else np.zeros(0, dtype=np.uint64)
-    return at, int(ends[-1]) if len(sizes) else 16
+    from . import api
+    sizes = np.ascontiguousarray(all_sizes, dtype=np.uint32)
+    frame_at = np.zeros(len(sizes), dtype=np.uint64)
+    total = C.c_uint64(0)
+    rc = api.lib().tsqa_frame_offsets(sizes.ctypes.data, len(sizes), frame_at.ctypes.data, C.byref(total))
+    if rc:
+        raise ValueError("a block stream size is out of range")
+    return frame_at, int(total.value)
 
 
 def walk_frames(container, limit: int):
     """The serial frame walk of a container in host memory (tsq_threads.cpp:513-524) over a numpy uint8 view.
-    -> (total, frame_at uint64[nb], sizes uint32[nb], ext uint32[nb], out_len uint32[nb]); raises ValueError."""
+    -> (total, frame_at uint64[nb], sizes uint32[nb], ext uint32[nb], out_len uint32[nb]); raises ValueError.
+    (C: tsqa_walk_frames -- no Python loop over the blocks.)"""
+    import ctypes as C
     import numpy as np
-    if limit < 16 or bytes(container[:4]) != b"TSQ1":
-        raise ValueError("bad magic")
-    nb = int.from_bytes(bytes(container[4:8]), "little")
-    total = int.from_bytes(bytes(container[8:16]), "little")
-    if nb == 0 or nb > (limit - 16) // 6:
-        raise ValueError("bad block count")
-    frame_at = np.zeros(nb, dtype=np.uint64)
-    sizes = np.zeros(nb, dtype=np.uint32)
-    ext = np.zeros(nb, dtype=np.uint32)
-    out_len = np.zeros(nb, dtype=np.uint32)
-    at = 16
-    for b in range(nb):
-        if at + 6 > limit:
-            raise ValueError("truncated")
-        h = bytes(container[at:at + 6])
-        frame = h[0] | h[1] << 8 | h[2] << 16
-        ln = frame & 0x7FFFFF
-        if ln < 3 or ln > OUTPUT_SZ or at + 3 + ln > limit:
-            raise ValueError("bad frame")
-        frame_at[b], sizes[b], ext[b] = at, ln, frame >> 23
-        out_len[b] = h[3] | h[4] << 8 | h[5] << 16
-        if out_len[b] > BLOCK_SZ:
-            raise ValueError("bad block size")
-        at += 3 + ln
-    if int(out_len.sum()) != total:
-        raise ValueError("sizes do not add up")
-    return total, frame_at, sizes, ext, out_len
+    from . import api
+    cap = max((limit - 16) // 6, 1) if limit >= 16 else 1
+    frame_at = np.zeros(cap, dtype=np.uint64)
+    sizes = np.zeros(cap, dtype=np.uint32)
+    ext = np.zeros(cap, dtype=np.uint32)
+    out_len = np.zeros(cap, dtype=np.uint32)
+    nb, total = C.c_uint32(0), C.c_uint64(0)
+    rc = api.lib().tsqa_walk_frames(container.ctypes.data, limit, cap, frame_at.ctypes.data, sizes.ctypes.data, ext.ctypes.data,
+                                    out_len.ctypes.data, C.byref(nb), C.byref(total))
+    if rc:
+        raise ValueError("malformed container")
+    k = nb.value
+    return int(total.value), frame_at[:k], sizes[:k], ext[:k], out_len[:k]
 
 
 class HostContainer:
@@ -194,11 +187,18 @@ class HostContainer:
         self.path = os.path.join("/dev/shm", name)
         self.size = size
         self.created = create
-        flags = os.O_RDWR | (os.O_CREAT | os.O_TRUNC if create else 0)
+        # the creator refuses an existing name (no truncation through a planted link) and reserves the space now: a /dev/shm that is
+        # too small raises OSError here, not SIGBUS at the first DMA
+        flags = os.O_RDWR | os.O_NOFOLLOW | (os.O_CREAT | os.O_EXCL if create else 0)
+        if create:
+            try:
+                os.unlink(self.path)                      # a leftover of a killed run of ours (same uid: the directory is sticky)
+            except FileNotFoundError:
+                pass
         fd = os.open(self.path, flags, 0o600)
         try:
             if create:
-                os.ftruncate(fd, size)
+                os.posix_fallocate(fd, 0, size)
             self.map = mmap.mmap(fd, size)
         finally:
             os.close(fd)
@@ -223,8 +223,9 @@ class HostContainer:
         self.array = None
         try:
             self.map.close()
-        except BufferError:
-            pass
+        except BufferError as e:                          # a numpy view of the mapping is still alive somewhere: say so
+            import warnings
+            warnings.warn(f"HostContainer {self.path}: mapping still referenced at close ({e})")
         if self.created:
             try:
                 os.unlink(self.path)
@@ -254,17 +255,13 @@ class DeviceBlocks:
         self.torch.cuda.synchronize(self.device)
         return self.sizes if self.collective_device == self.device else self.sizes.to(self.collective_device)
 
-    def frames_to_host(self, sizes, frame_at, ext, host):
-        self.codec.frames_to_host_async(self.slots, sizes, frame_at, ext, host.ptr)
+    def place(self, all_sizes, layout, ext, host) -> int:
+        """Every owned frame to its place in the host container (tsqa_sharded_place_async).  -> container size."""
+        return self.codec.sharded_place_async(self.slots, all_sizes, layout.n_total, layout.rank, layout.world, ext, host.ptr, host.size)
 
-    def frames_from_host(self, host, frame_at, sizes):
-        self.codec.frames_from_host_async(host.ptr, frame_at, sizes, self.slots)
-
-    def decode(self, frames_np, n_local, d_out):
-        t = self.torch
-        d_frames = t.from_numpy(frames_np.view("uint8")).to(self.device, non_blocking=False)
-        self.codec.decode_blocks_async(self.slots, d_frames, n_local, d_out)
-        self._keep = d_frames
+    def fetch_decode(self, host, container_size, layout, d_out) -> int:
+        """Frame walk, owned frames to the device, decode (tsqa_sharded_fetch_decode_async).  -> uncompressed size of the job."""
+        return self.codec.sharded_fetch_decode_async(host.ptr, container_size, layout.rank, layout.world, self.slots, d_out)
 
     def sync(self):
         self.torch.cuda.synchronize(self.device)
@@ -285,15 +282,28 @@ class ShardedCodec:
     def __init__(self, layout: ShardLayout, blocks, host: HostContainer, ext: int):
         self.layout, self.blocks, self.host, self.ext = layout, blocks, host, int(ext)
         blocks.alloc(layout.n_local)
+        # wall seconds spent per phase on this rank (the calls below already end in a device sync where one is needed)
+        self.seconds = {"encode": 0.0, "size_gather": 0.0, "place_d2h": 0.0, "fetch_h2d_decode": 0.0}
 
     def _all_sizes(self):
         """Every block's stream size, on every rank: ONE all-gather of max_blocks u32 per rank."""
+        import time
         import numpy as np
         lay = self.layout
-        mine = self.blocks.sizes_tensor()
+        t0 = time.perf_counter()
+        mine = self.blocks.sizes_tensor()                # (waits for the encode kernel)
+        t1 = time.perf_counter()
+        self.seconds["encode"] += t1 - t0
+        try:
+            return self._gather_sizes(mine)
+        finally:
+            self.seconds["size_gather"] += time.perf_counter() - t1
+
+    def _gather_sizes(self, mine):
+        import numpy as np
+        lay = self.layout
         if lay.world == 1:
-            local = mine.cpu().numpy().astype(np.uint32)[:lay.n_local]
-            return local.copy()
+            return np.ascontiguousarray(mine.cpu().numpy().astype(np.uint32)[:lay.n_local])
         import torch
         import torch.distributed as dist
         pad = torch.zeros(lay.max_blocks, dtype=mine.dtype, device=mine.device)
@@ -301,46 +311,32 @@ class ShardedCodec:
         every = torch.empty(lay.world * lay.max_blocks, dtype=mine.dtype, device=mine.device)
         dist.all_gather_into_tensor(every, pad)
         table = every.cpu().numpy().astype(np.uint32).reshape(lay.world, lay.max_blocks)
-        out = np.zeros(lay.nb, dtype=np.uint32)
-        for r in range(lay.world):
-            owned = rank_blocks(lay.nb, r, lay.world)
-            out[owned] = table[r, :len(owned)]
-        return out
+        # block b = k * world + r is entry (r, k): the transpose, flattened, is the job's block order
+        return np.ascontiguousarray(table.T.reshape(-1)[:lay.nb])
 
     def compress(self, d_shard) -> int:
         """Encode the owned blocks and put their frames into the host container.  Returns the container size
         (the same on every rank).  The caller barriers before anyone reads the container."""
-        import numpy as np
         lay = self.layout
         if lay.n_local:
             self.blocks.encode(d_shard, lay.n_local, lay.stride, lay.last_len, self.ext)
+        import time
         sizes = self._all_sizes()
-        frame_at, total = frame_offsets(sizes)
-        if total > self.host.size:
-            raise ValueError("host container too small")
-        if lay.rank == 0:                                         # tsq_threads.cpp:333-335
-            self.host.array[:16] = np.frombuffer(b"TSQ1" + lay.nb.to_bytes(4, "little") + lay.n_total.to_bytes(8, "little"), dtype=np.uint8)
-        if lay.n_local:
-            own = np.asarray(lay.blocks)
-            self.blocks.frames_to_host(np.ascontiguousarray(sizes[own]), np.ascontiguousarray(frame_at[own]), self.ext, self.host)
+        t0 = time.perf_counter()
+        total = self.blocks.place(sizes, lay, self.ext, self.host)
         self.blocks.sync()
+        self.seconds["place_d2h"] += time.perf_counter() - t0
         return total
 
     def decompress(self, container_size: int, d_out) -> int:
         """Walk the container, bring the owned frames to the device, decode them back to back into d_out.
         Returns the job's uncompressed size."""
-        import numpy as np
+        import time
         lay = self.layout
-        total, frame_at, sizes, ext, out_len = walk_frames(self.host.array, container_size)
-        if len(sizes) != lay.nb or total != lay.n_total:
+        t0 = time.perf_counter()
+        total = self.blocks.fetch_decode(self.host, container_size, lay, d_out)
+        if total != lay.n_total:
             raise ValueError("container does not match the layout")
-        if lay.n_local:
-            own = np.asarray(lay.blocks)
-            self.blocks.frames_from_host(self.host, np.ascontiguousarray(frame_at[own]), np.ascontiguousarray(sizes[own]))
-            fr = np.zeros(lay.n_local, dtype=FRAME_DTYPE)
-            fr["stream_at"] = np.arange(lay.n_local, dtype=np.uint64) * OUTPUT_SZ
-            fr["out_at"] = np.arange(lay.n_local, dtype=np.uint64) * BLOCK_SZ
-            fr["stream_len"], fr["ext"], fr["out_len"] = sizes[own], ext[own], out_len[own]
-            self.blocks.decode(fr, lay.n_local, d_out)
         self.blocks.sync()
+        self.seconds["fetch_h2d_decode"] += time.perf_counter() - t0
         return total
