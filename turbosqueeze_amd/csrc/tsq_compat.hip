@@ -275,7 +275,7 @@ public:
     bool start() {
         std::vector<int> devs = device_list();
         n_devices_ = (uint32_t)devs.size();
-        size_t per_dev = env_size("TSQ_AMD_LANES", 2);
+        size_t per_dev = env_size("TSQ_AMD_LANES", 4);
         for (size_t k = 0; k < per_dev * devs.size(); ++k) {
             Lane l;
             if (!l.init(devs[k % devs.size()])) { l.destroy(); for (auto& x : lanes_) x.destroy(); lanes_.clear(); return false; }
@@ -319,6 +319,14 @@ private:
     // and the host gathers the slices in block order).
     uint32_t job_batch(uint32_t nb, bool through_files) const {
         uint32_t batch = through_files ? file_batch_blocks_ : batch_blocks_;
+        // Memory-mode jobs are cut into one batch per pipeline lane (at least 32 blocks each): the lanes' streams overlap one
+        // batch's copy to the device, another's kernels and a third's copy back (PCIe is full duplex; the kernels of different
+        // lanes run side by side), which a single device-filling batch cannot -- its three phases would run one after the other.
+        if (!through_files && !lanes_.empty()) {
+            const uint32_t per_lane = (nb + (uint32_t)lanes_.size() - 1) / (uint32_t)lanes_.size();
+            const uint32_t cut = per_lane < 32u ? 32u : per_lane;
+            if (cut < batch) batch = cut;
+        }
         if (n_devices_ > 1) {
             const uint32_t per_dev = (nb + n_devices_ - 1) / n_devices_;
             if (per_dev < batch) batch = per_dev ? per_dev : 1;
@@ -464,21 +472,25 @@ private:
         if (j.outfile) { if (!sink.open_file_buffered(j.out_path.c_str(), (size_t)total + 128)) return false; }
         else if (!sink.open_mem((size_t)total + 128)) return false;                            // tsq_threads.cpp:795
 
-        bool ok = true;
+        Marks mk; mk.at("decompress: buffers opened");
+        std::atomic<bool> ok{true};
         std::deque<InFlight> fly;
+        std::mutex fly_m;
+        std::condition_variable fly_cv;
+        bool fly_closed = false;
         uint32_t done_blocks = 0;
         const bool stage_in = src.mem == nullptr, stage_out = sink.mem == nullptr;
         const uint32_t batch = job_batch(nb, stage_in || stage_out);
         Prefault touch;
         bool touching = false;
-        auto drain_one = [&]() {
-            InFlight f = fly.front(); fly.pop_front();
+        auto drain = [&](const InFlight& f) {
             Lane& l = lanes_[f.lane];
             (void)hipSetDevice(l.dev->device);
             if (hipEventSynchronize(l.ev) != hipSuccess || *l.h_status != 0) { ok = false; return; }
+            mk.at("decompress: kernels done");
             // the blocks come back in pieces of a few blocks, in order; each block reports progress once it has landed
             // (tsq_threads.cpp:648-655: the writer copies a block out, then calls progress_cb)
-            if (!stage_out) touch.join();
+            if (!stage_out) { touch.join(); mk.at("decompress: output pages touched"); }
             uint8_t* dst = stage_out ? nullptr : sink.claim(f.out_bytes);
             if (!stage_out && !dst) { ok = false; return; }
             const FrameInfo* fr = l.h_frames;
@@ -496,13 +508,42 @@ private:
                     if (j.progress) j.progress(j.id, (double)done_blocks / (double)nb);
                 }
             }
+            mk.at("decompress: D2H done");
         };
 
+        // The copies back run on their own thread (the reference's writer thread, tsq_threads.cpp:604-676): a copy from or to the
+        // caller's pageable memory holds the calling thread for its whole duration, so with one thread the copies to the device of
+        // the later batches and the copies back of the earlier ones would take turns on a link that can do both at once.
+        std::thread drainer([&]() {
+            for (;;) {
+                InFlight f;
+                {
+                    std::unique_lock<std::mutex> g(fly_m);
+                    fly_cv.wait(g, [&] { return fly_closed || !fly.empty(); });
+                    if (fly.empty()) return;
+                    f = fly.front();
+                }
+                if (ok) drain(f);
+                {
+                    std::lock_guard<std::mutex> g(fly_m);
+                    fly.pop_front();                                  // only now may the lane be used again
+                }
+                fly_cv.notify_all();
+            }
+        });
+        auto close_drainer = [&]() {
+            { std::lock_guard<std::mutex> g(fly_m); fly_closed = true; }
+            fly_cv.notify_all();
+            if (drainer.joinable()) drainer.join();
+        };
         size_t at = 16;                       // container cursor: the frame walk is serial (tsq_threads.cpp:513-524)
         uint64_t produced = 0;
         for (uint32_t b0 = 0, k = 0; b0 < nb && ok; ++k) {
             const size_t lane_i = k % lanes_.size();
-            while (ok && fly.size() >= lanes_.size()) drain_one();
+            {
+                std::unique_lock<std::mutex> g(fly_m);
+                fly_cv.wait(g, [&] { return fly.size() < lanes_.size(); });
+            }
             if (!ok) break;
             Lane& l = lanes_[lane_i];
             // sized by what is left of the job, not by the configured batch (a one-block container must not reserve gigabytes)
@@ -543,10 +584,15 @@ private:
             if (l.dev->launch_decode(l.d_in, bn, l.d_out, l.dev->d_status, s) != TSQA_OK) { ok = false; break; }
             (void)hipMemcpyAsync(l.h_status, l.dev->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s);
             if (hipEventRecord(l.ev, s) != hipSuccess) { ok = false; break; }
-            fly.push_back({lane_i, b0, bn, out_bytes});
+            mk.at("decompress: H2D + kernels issued");
+            {
+                std::lock_guard<std::mutex> g(fly_m);
+                fly.push_back({lane_i, b0, bn, out_bytes});
+            }
+            fly_cv.notify_all();
             produced += out_bytes; at += cur; b0 += bn;
         }
-        while (ok && !fly.empty()) drain_one();
+        close_drainer();                                              // (drains what is in flight first)
         for (auto& l : lanes_) { (void)hipSetDevice(l.dev->device); (void)hipStreamSynchronize(l.dev->stream); }
         touch.join();                                                 // nobody may still be touching the buffer when it is freed
         if (ok && produced != total) ok = false;
