@@ -196,8 +196,9 @@ int tsqa_measure_copy(tsqa_ctx *ctx, size_t bytes, int reps, double *best_gbps, 
 /* Kernel variant selection.  Encoder: 0 = default (eleven-wave staged encoder; its lean layout by itself when there are
  * more blocks than CUs), 1 = serial kernel (one lane walks the block; correctness baseline), 6 = force the lean layout
  * (two blocks per CU), 7 = never lean.  Decoder: 0 = default (byte-lane decoder; on two workgroups per block when a
- * launch has at most half as many blocks as the device has CUs), 1 = serial kernel, 3 = always two workgroups per block,
- * 4 = always one.  Superseded kernel generations (encoder 5 = round 2's five-wave encoder; decoder 8, 9 = round 1's
+ * launch has at most half as many blocks as the device has CUs, three -- two of them parsing alternate windows of the stream --
+ * when it has at most a third), 1 = serial kernel, 3 = several workgroups per block whatever the block count (three when the
+ * CUs allow), 4 = always one, 5 = always three, 6 = always two.  Superseded kernel generations (encoder 5 = round 2's five-wave encoder; decoder 8, 9 = round 1's
  * byte-granular ring decoder) exist only in the A/B library built by `make ab`; the product library rejects them. */
 void tsqa_set_kernel_variant(tsqa_ctx *ctx, int encode_variant, int decode_variant);
 

@@ -339,7 +339,7 @@ def test_all_kernel_variants_agree(tsq, oracle):
     host = np.concatenate([tsq.synth.text(6_000_000, seed=21), tsq.synth.mix(3_000_000, seed=22)])
     dev = to_dev(host)
     want = {ext: oracle.compress(host, ext, threads=4) for ext in (0, 1)}
-    for ab, variants in ((False, ((0, 0), (1, 1), (6, 0), (7, 0))), (True, ((0, 0), (5, 8), (5, 9)))):
+    for ab, variants in ((False, ((0, 0), (1, 1), (6, 3), (7, 4), (0, 5), (0, 6))), (True, ((0, 0), (5, 8), (5, 9)))):
         assert os.path.exists(tsq.lib_path(ab)), "run __graft_entry__.build() first"
         c = tsq.DeviceCodec(0, ab=ab)
         for ext in (0, 1):

@@ -84,13 +84,13 @@ if "--no-time" not in sys.argv:
         assert torch.equal(back, src)
         print(f"TIME text 1e9 ext={ext}: encode kernel {em / max(en, 1):.2f} ms, decode kernel {dm / max(dn, 1):.3f} ms, ratio {blob.numel() / len(host):.4f}", flush=True)
 if "--no-time" not in sys.argv:
-    # few blocks: the two-workgroup decoder (variant 3) against the one-workgroup one (variant 4)
+    # few blocks: one workgroup per block (variant 4), PARSE + COPY (6), two PARSE + COPY where the CUs allow (3)
     for nb in (30, 60, 120):
         host = tsq.synth.text(nb * B, 2)
         src = torch.from_numpy(host).cuda()
         blob = codec.compress(src, 0)
         line = f"TIME decode {nb} blocks:"
-        for dv in (4, 3):
+        for dv in (4, 6, 3):
             codec.set_variant(0, dv)
             back = codec.decompress(blob)
             codec.profile_read()

@@ -28,17 +28,29 @@ struct DuoCfg {
     static constexpr uint32_t SLOTS = 4;                                   // chunk records in flight per block
     static constexpr uint32_t HDR = 8;                                     // header words: 0 sp, 1 op, 2 groups, 3 next op, 4 flags, 5 next sp
     static constexpr uint32_t REC_WORDS = ((HDR + 5 * SymCfg::MAXG) + 63u) & ~63u;
-    static constexpr uint32_t FLAG_STRIDE = 64;                            // u32 words per block: [0] chunks produced, [32] chunks consumed
+    static constexpr uint32_t FLAG_STRIDE = 64;                            // u32 words per block: [0] records produced, [32] records consumed,
+                                                                           // [8 + 8 p ..]: the entry mailbox of PARSE workgroup p (sequence, delta | flags << 16, op, record)
     static constexpr uint32_t kLast = 1, kError = 2;
     static constexpr uint32_t kAbort = 0xFFFFFFFFu;
     static constexpr uint32_t kSpinLimit = 1u << 24;                       // polls (with s_sleep) before a wait gives up: seconds
 };
 
-__device__ __forceinline__ uint32_t duo_load_acquire(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+// polls are relaxed loads (an acquire load invalidates the CU's vector cache every time: hundreds of polling workgroups would keep
+// the L2 busy with nothing); one acquire fence follows the poll that succeeds
+__device__ __forceinline__ uint32_t duo_load_acquire(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void duo_acquire_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 __device__ __forceinline__ void duo_store_release(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ------------------------------------------------------------------------------------------------------------------ PARSE
-__device__ __forceinline__ void duo_parse(const uint8_t* __restrict__ in, uint32_t in_len, uint32_t size, uint32_t ext,
+// The stream is parsed in FIXED windows: window k covers stream offsets [3 + k S, 3 + (k + 1) S + pad).  The speculative part of the
+// parse (P0..P2: every offset parsed as if a group started there, pointer doubling) does not depend on where the chunk's first group
+// really starts, only the chain (P3) and the groups (P4) do -- and the first group of window k + 1 starts less than 133 bytes into it
+// (where the last group of window k ends).  So NP PARSE workgroups take the windows in turn: each prepares its window on its own and
+// waits only for the ENTRY (offset of the first group, output position, record number) that the workgroup of the window before
+// publishes as soon as its own chain has reached its window's end.  The block's serial parse chain is then P3 + P4 per window.
+// NP = 1: the same code, the entry is handed over in registers.
+template <uint32_t NP>
+__device__ __forceinline__ void duo_parse(const uint8_t* __restrict__ in, uint32_t in_len, uint32_t size, uint32_t ext, uint32_t me,
                                           uint32_t* __restrict__ ring_g, uint32_t* __restrict__ flags, int32_t* __restrict__ status, uint8_t* lds)
 {
     using C = SymCfg;
@@ -58,39 +70,57 @@ __device__ __forceinline__ void duo_parse(const uint8_t* __restrict__ in, uint32
     uint16_t* const lut = reinterpret_cast<uint16_t*>(lds + SymLds::lut);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
 
-    if (size == 0u) return;                              // (an empty block has no chunks: neither workgroup has anything to do)
+    if (size == 0u) return;                              // (an empty block has no chunks: no workgroup has anything to do)
     if (tid == 0) misc[4] = 0;
     { uint32_t sl, ol; pair_lens(tid & 255u, tid >> 8, 0u, sl, ol); lut[tid] = (uint16_t)sl; }
-    uint32_t sp = 3, op = 0, k = 0;
+    // the entry of this workgroup's next window, when it is handed over in registers (NP == 1, or window 0)
+    uint32_t e_delta = 0, e_op = 0, e_rec = 0;
+    bool e_known = me == 0u;
+    uint32_t* const entry_in = flags + 8u + 8u * me;                        // [0] sequence, [1] delta | flags << 16, [2] op, [3] record number
+    uint32_t* const entry_out = flags + 8u + 8u * ((me + 1u) % NP);
+    uint32_t n_in = 0, n_out = 0;                                           // entries received / sent so far
+    // whole 16-byte words of window q, loaded an iteration ahead (the windows lie at fixed places)
     uint4 pre = make_uint4(0, 0, 0, 0);
-    auto prefetch = [&](uint32_t at) {
-        const uint32_t avail = in_len - at;
-        const uint32_t lim = avail < C::S + C::SPAD ? avail : C::S + C::SPAD;
+    auto prefetch = [&](uint32_t q) {
+        const uint64_t at = 3ull + (uint64_t)q * C::S;
         pre = make_uint4(0, 0, 0, 0);
+        if (at >= in_len) return;
+        const uint32_t av = in_len - (uint32_t)at;
+        const uint32_t lim = av < C::S + C::SPAD ? av : C::S + C::SPAD;
         if (tid < C::SWORDS && (tid << 4) + 16u <= lim) __builtin_memcpy(&pre, in + at + (tid << 4), 16);
     };
-    prefetch(sp);
+    prefetch(me);
+    auto give_up = [&](uint32_t why) {
+        // (uniform: every thread calls it) tell the others and leave
+        if (tid == 0) {
+            if (why == 2u) atomicMax(status, kErrStream);
+            duo_store_release(flags + 32, DuoCfg::kAbort);
+        }
+    };
     __syncthreads();
 
-    while (op < size) {
-        // ---------------- P0: the chunk (loaded a chunk ago) goes to LDS.  sbuf[k] = in[sp + k]; zeros beyond the stream.
-        const uint32_t avail = in_len - sp;
+    for (uint32_t k = me;; k += NP) {
+        const uint64_t w64 = 3ull + (uint64_t)k * C::S;
+        const bool beyond = w64 >= in_len;                                   // no such window: only the "finished" entry can come
+        const uint32_t W = beyond ? in_len : (uint32_t)w64;
+        const uint32_t avail = in_len - W;
         const uint32_t slim = avail < C::S ? avail : C::S;
         uint8_t* const sbuf = s_raw;
-        if (tid < C::SWORDS) {
-            uint4 w = pre;
-            const uint32_t lim = avail < C::S + C::SPAD ? avail : C::S + C::SPAD, o = tid << 4;
-            if (o < lim && o + 16u > lim) {                                       // the stream's last, partial word (once per block)
-                uint32_t b[4] = {0, 0, 0, 0};
-                for (uint32_t q = 0; o + q < lim; ++q) b[q >> 2] |= (uint32_t)in[sp + o + q] << (8u * (q & 3u));
-                w = make_uint4(b[0], b[1], b[2], b[3]);
+        if (!beyond) {
+            // ---------------- P0: the window (loaded an iteration ago) goes to LDS.  sbuf[q] = in[W + q]; zeros beyond the stream.
+            if (tid < C::SWORDS) {
+                uint4 w = pre;
+                const uint32_t lim = avail < C::S + C::SPAD ? avail : C::S + C::SPAD, o = tid << 4;
+                if (o < lim && o + 16u > lim) {                                  // the stream's last, partial word (once per block)
+                    uint32_t b[4] = {0, 0, 0, 0};
+                    for (uint32_t q = 0; o + q < lim; ++q) b[q >> 2] |= (uint32_t)in[W + o + q] << (8u * (q & 3u));
+                    w = make_uint4(b[0], b[1], b[2], b[3]);
+                }
+                *reinterpret_cast<uint4*>(s_raw + (tid << 4)) = w;
             }
-            *reinterpret_cast<uint4*>(s_raw + (tid << 4)) = w;
-        }
-        if (tid == 0) { misc[0] = 0; misc[1] = 0; misc[2] = 0xFFFFFFFFu; misc[3] = 0xFFFFFFFFu; misc[5] = 0; }
-        __syncthreads();
-        // ---------------- P1 + P2: speculative group parse at every offset, then next^2 .. next^16 (tsq_dec_sym.cuh)
-        {
+            prefetch(k + NP);                                                    // this workgroup's next window is on its way
+            __syncthreads();
+            // ---------------- P1 + P2: speculative group parse at every offset, then next^2 .. next^16 (tsq_dec_sym.cuh)
             uint32_t x[C::PER], y[C::PER], c[C::PER];
 #pragma unroll
             for (uint32_t q = 0; q < C::PER; ++q) { const uint32_t o = tid + q * C::T; c[q] = sbuf[o]; x[q] = o + 1u; }
@@ -123,98 +153,147 @@ __device__ __forceinline__ void duo_parse(const uint8_t* __restrict__ in, uint32
                 srcj = dsts[d];
             }
         }
-        // ---------------- P3: one lane follows next^16 from the chunk start
-        if (tid == 0) {
-            uint32_t x = 0, q = 0;
-            while (x < slim && q < C::MAXSN) { sn[q++] = (uint16_t)x; x = j16[x]; }
-            misc[0] = q;
-            if (q >= C::MAXSN && x < slim) misc[4] = kErrStream;
-        }
-        __syncthreads();
-        const uint32_t nsn = misc[0];
-        // ---------------- P4: one lane per group
-        {
-            uint32_t x = C::TERM;
-            if (tid < nsn * C::HOP) {
-                x = sn[tid >> 4];
-                if (tid & 8u) x = x < slim ? j8[x] : C::TERM;
-                if (tid & 4u) x = x < slim ? j4[x] : C::TERM;
-                if (tid & 2u) x = x < slim ? j2[x] : C::TERM;
-                if (tid & 1u) x = x < slim ? (uint32_t)(x + j1[x]) : C::TERM;
-            }
-            uint32_t v = 0;
-            if (x < slim) {
-                gstart[tid] = (uint16_t)x;
-                const uint32_t c = sbuf[x];
-                uint32_t p = x + 1u, pw[4];
-#pragma unroll
-                for (uint32_t pr = 0; pr < 4; ++pr) {
-                    const uint32_t cc = (c >> (6u - 2u * pr)) & 3u;
-                    pw[pr] = p | (v << 13) | (cc << 30);
-                    uint32_t sl, ol;
-                    pair_lens(sbuf[p], cc, ext, sl, ol);
-                    p += sl;
-                    v += ol;
+        // ---------------- the window's entry: where its first group starts, the output position there, the record number
+        uint32_t delta, op, rec_no;
+        if (e_known) { delta = e_delta; op = e_op; rec_no = e_rec; e_known = false; }
+        else {
+            if (tid == 0) {
+                uint32_t why = 0, spins = 0;
+                for (;;) {
+                    if (duo_load_acquire(entry_in) > n_in) break;
+                    if ((spins & 63u) == 63u && (duo_load_acquire(flags + 32) == DuoCfg::kAbort || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { why = 1; break; }
+                    if (++spins > DuoCfg::kSpinLimit) { why = 2; break; }
+                    __builtin_amdgcn_s_sleep(1);
                 }
-                *reinterpret_cast<uint4*>(pairs + tid * 4u) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
-                glen[tid] = (uint16_t)v;
-                if (p >= slim) { misc[1] = tid + 1u; misc[5] = p; }
+                duo_acquire_fence();
+                misc[6] = why;
+                if (!why) { misc[7] = __builtin_nontemporal_load(entry_in + 1); misc[8] = __builtin_nontemporal_load(entry_in + 2); misc[9] = __builtin_nontemporal_load(entry_in + 3); }
             }
-            const uint32_t incl = wave_scan_add(v);
-            if (lane == 63) wsum[wid] = incl;
             __syncthreads();
-            const uint32_t totals = wave_scan_add(lane < C::T / 64u ? wsum[lane] : 0u);
-            const uint32_t before = wid ? (uint32_t)__builtin_amdgcn_readlane((int)totals, (int)wid - 1) : 0u;
-            const uint32_t excl = before + incl - v;
-            if (x < slim) {
-                gout[tid] = op + excl;
-                if (excl + 512u + 16u > C::OUTC) atomicMin(&misc[2], tid);
-                if (op + excl + v >= size) atomicMin(&misc[3], tid);
+            if (misc[6] != 0) { give_up(misc[6]); return; }
+            n_in++;
+            const uint32_t d = misc[7];
+            if (d >> 16) return;                                                 // finished (or failed) in an earlier window
+            delta = d & 0xFFFFu; op = misc[8]; rec_no = misc[9];
+            __syncthreads();                                                     // (misc[7..9] are read: they may be written again)
+        }
+        if (beyond) {                                                            // the chain runs past the stream's end: malformed
+            if (tid == 0) atomicMax(status, kErrStream);
+            // tell the COPY workgroup (through a record, in order)
+            // (fall through to the hand-over below with `bad`)
+        }
+        // ---------------- the chunks of this window: normally one; more when the LDS image budget of the COPY workgroup cuts one short
+        for (;;) {
+            if (tid == 0) { misc[0] = 0; misc[1] = 0; misc[2] = 0xFFFFFFFFu; misc[3] = 0xFFFFFFFFu; misc[5] = 0; }
+            __syncthreads();
+            // ---------------- P3: one lane follows next^16 from the chunk's first group
+            if (tid == 0 && !beyond) {
+                uint32_t x = delta, q = 0;
+                while (x < slim && q < C::MAXSN) { sn[q++] = (uint16_t)x; x = j16[x]; }
+                misc[0] = q;
+                if (q >= C::MAXSN && x < slim) misc[4] = kErrStream;
             }
-        }
-        __syncthreads();
-        uint32_t ng = misc[1];
-        uint32_t next_sp, next_op;
-        bool last_chunk = false;
-        {
-            const uint32_t cut = misc[2], fin = misc[3];
-            if (fin != 0xFFFFFFFFu && fin < cut) { ng = fin + 1; last_chunk = true; next_sp = sp; next_op = size; }
-            else if (cut != 0xFFFFFFFFu) { ng = cut; next_sp = sp + gstart[cut]; next_op = gout[cut]; }
-            else { next_sp = sp + misc[5]; next_op = ng ? gout[ng - 1] + glen[ng - 1] : op; }
-        }
-        const bool bad = misc[4] != 0 || ng == 0 || (!last_chunk && next_sp >= in_len);
-        if (!bad && !last_chunk) prefetch(next_sp);
-        // ---------------- hand the chunk to the COPY workgroup
-        if (tid == 0) {
-            uint32_t give_up = 0, spins = 0;
-            for (;;) {
-                const uint32_t done = duo_load_acquire(flags + 32);
-                if (done == DuoCfg::kAbort || ((spins & 255u) == 255u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { give_up = 1; break; }
-                if (k - done < DuoCfg::SLOTS) break;
-                if (++spins > DuoCfg::kSpinLimit) { give_up = 2; break; }
-                __builtin_amdgcn_s_sleep(4);
+            __syncthreads();
+            const uint32_t nsn = misc[0];
+            // ---------------- P4: one lane per group
+            {
+                uint32_t x = C::TERM;
+                if (tid < nsn * C::HOP) {
+                    x = sn[tid >> 4];
+                    if (tid & 8u) x = x < slim ? j8[x] : C::TERM;
+                    if (tid & 4u) x = x < slim ? j4[x] : C::TERM;
+                    if (tid & 2u) x = x < slim ? j2[x] : C::TERM;
+                    if (tid & 1u) x = x < slim ? (uint32_t)(x + j1[x]) : C::TERM;
+                }
+                uint32_t v = 0;
+                if (x < slim) {
+                    gstart[tid] = (uint16_t)x;
+                    const uint32_t c = sbuf[x];
+                    uint32_t p = x + 1u, pw[4];
+#pragma unroll
+                    for (uint32_t pr = 0; pr < 4; ++pr) {
+                        const uint32_t cc = (c >> (6u - 2u * pr)) & 3u;
+                        pw[pr] = p | (v << 13) | (cc << 30);
+                        uint32_t sl, ol;
+                        pair_lens(sbuf[p], cc, ext, sl, ol);
+                        p += sl;
+                        v += ol;
+                    }
+                    *reinterpret_cast<uint4*>(pairs + tid * 4u) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+                    glen[tid] = (uint16_t)v;
+                    if (p >= slim) { misc[1] = tid + 1u; misc[5] = p; }
+                }
+                const uint32_t incl = wave_scan_add(v);
+                if (lane == 63) wsum[wid] = incl;
+                __syncthreads();
+                const uint32_t totals = wave_scan_add(lane < C::T / 64u ? wsum[lane] : 0u);
+                const uint32_t before = wid ? (uint32_t)__builtin_amdgcn_readlane((int)totals, (int)wid - 1) : 0u;
+                const uint32_t excl = before + incl - v;
+                if (x < slim) {
+                    gout[tid] = op + excl;
+                    if (excl + 512u + 16u > C::OUTC) atomicMin(&misc[2], tid);
+                    if (op + excl + v >= size) atomicMin(&misc[3], tid);
+                }
             }
-            misc[6] = give_up;
+            __syncthreads();
+            uint32_t ng = misc[1];
+            uint32_t next_op, next_delta = 0;
+            bool last_chunk = false, cut_short = false;
+            {
+                const uint32_t cut = misc[2], fin = misc[3];
+                if (fin != 0xFFFFFFFFu && fin < cut) { ng = fin + 1; last_chunk = true; next_op = size; }
+                else if (cut != 0xFFFFFFFFu) { ng = cut; cut_short = true; next_delta = gstart[cut]; next_op = gout[cut]; }
+                else { next_delta = misc[5] - C::S; next_op = ng ? gout[ng - 1] + glen[ng - 1] : op; }
+            }
+            // (a chunk that neither completes the block nor is cut short must have run to the end of a FULL window)
+            const bool bad = beyond || misc[4] != 0 || ng == 0 || (!last_chunk && !cut_short && (slim < C::S || misc[5] < C::S || next_delta >= C::SPAD));
+            // ---------------- the next window's workgroup gets its entry as early as possible
+            if (!cut_short || bad) {
+                const uint32_t fl = bad ? 2u : last_chunk ? 1u : 0u;
+                if (NP == 1u) {
+                    if (fl) { /* nothing to hand over */ } else { e_delta = next_delta; e_op = next_op; e_rec = rec_no + 1u; e_known = true; }
+                } else {
+                    if (tid == 0) {
+                        __builtin_nontemporal_store((fl << 16) | next_delta, entry_out + 1);
+                        __builtin_nontemporal_store(next_op, entry_out + 2);
+                        __builtin_nontemporal_store(rec_no + 1u, entry_out + 3);
+                        duo_store_release(entry_out, n_out + 1u);
+                    }
+                    n_out++;
+                }
+            }
+            // ---------------- hand the chunk to the COPY workgroup: records go out in order, into a free slot
+            if (tid == 0) {
+                uint32_t why = 0, spins = 0;
+                for (;;) {
+                    const uint32_t done = duo_load_acquire(flags + 32);
+                    if (done == DuoCfg::kAbort || ((spins & 255u) == 255u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { why = 1; break; }
+                    if (rec_no - done < DuoCfg::SLOTS && (NP == 1u || duo_load_acquire(flags) == rec_no)) break;
+                    if (++spins > DuoCfg::kSpinLimit) { why = 2; break; }
+                    __builtin_amdgcn_s_sleep(8);                                   // (nobody waits for this workgroup while its ring is full)
+                }
+                duo_acquire_fence();
+                misc[6] = why;
+            }
+            __syncthreads();
+            if (misc[6] != 0) { give_up(misc[6]); return; }
+            uint32_t* const rec = ring_g + (size_t)(rec_no % DuoCfg::SLOTS) * DuoCfg::REC_WORDS;
+            if (!bad) {
+                for (uint32_t w = tid; w < 4u * ng; w += C::T) rec[DuoCfg::HDR + w] = pairs[w];
+                for (uint32_t w = tid; w < ng; w += C::T) rec[DuoCfg::HDR + 4u * C::MAXG + w] = gout[w];
+            }
+            if (tid == 0) {
+                rec[0] = W; rec[1] = op; rec[2] = ng; rec[3] = next_op;
+                rec[4] = (last_chunk ? DuoCfg::kLast : 0u) | (bad ? DuoCfg::kError : 0u);
+                rec[5] = cut_short ? W : W + C::S;                            // where the next record's window starts (for the COPY side's prefetch)
+            }
+            __syncthreads();                                 // every thread's record stores are complete (the barrier waits for them) ...
+            if (tid == 0) duo_store_release(flags, rec_no + 1u);            // ... and thread 0 publishes them
+            if (bad) { if (tid == 0) atomicMax(status, kErrStream); return; }
+            if (last_chunk) return;
+            if (!cut_short) break;
+            delta = next_delta; op = next_op; rec_no++;
         }
-        __syncthreads();
-        if (misc[6] != 0) { if (tid == 0 && misc[6] == 2) atomicMax(status, kErrStream); return; }
-        uint32_t* const rec = ring_g + (size_t)(k % DuoCfg::SLOTS) * DuoCfg::REC_WORDS;
-        if (!bad) {
-            for (uint32_t w = tid; w < 4u * ng; w += C::T) rec[DuoCfg::HDR + w] = pairs[w];
-            for (uint32_t w = tid; w < ng; w += C::T) rec[DuoCfg::HDR + 4u * C::MAXG + w] = gout[w];
-        }
-        if (tid == 0) {
-            rec[0] = sp; rec[1] = op; rec[2] = ng; rec[3] = next_op;
-            rec[4] = (last_chunk ? DuoCfg::kLast : 0u) | (bad ? DuoCfg::kError : 0u);
-            rec[5] = next_sp;
-        }
-        __syncthreads();                                 // every thread's record stores are complete (the barrier waits for them) ...
-        k++;
-        if (tid == 0) duo_store_release(flags, k);        // ... and thread 0 publishes them
-        if (bad) { if (tid == 0) atomicMax(status, kErrStream); return; }
-        op = next_op;
-        sp = next_sp;
-        if (last_chunk) break;
     }
 }
 
@@ -246,7 +325,9 @@ __device__ __forceinline__ void duo_copy(const uint8_t* __restrict__ in, uint32_
     const uint32_t oskew = (uint32_t)((uintptr_t)out & 15u);
     uint32_t ring_op = oskew;
     uint32_t prev_op = 0, prev_len = 0, prev_ring = 0;
-    uint32_t k = 0;
+    uint32_t k = 0, made_seen = 0;
+    uint32_t hdr_n[6] = {0, 0, 0, 0, 0, 0}, pw_n[2] = {0, 0}, go_n[2] = {0, 0};
+    bool have_next = false;
     if (size == 0u) return;
     if (tid == 0) { misc[4] = 0; }
 
@@ -279,35 +360,46 @@ __device__ __forceinline__ void duo_copy(const uint8_t* __restrict__ in, uint32_
     __syncthreads();
 
     for (;;) {
-        // ---------------- the previous chunk's bytes go to HBM while thread 0 waits for this chunk's record
+        // ---------------- the previous chunk's bytes go to HBM; thread 0 waits for this chunk's record, if it is not known to be there
         flush_image();
-        if (tid == 0) {
-            uint32_t give_up = 0, spins = 0;
-            for (;;) {
-                const uint32_t made = duo_load_acquire(flags);
-                if (made > k) break;
-                if ((spins & 255u) == 255u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { give_up = 1; break; }
-                if (++spins > DuoCfg::kSpinLimit) { give_up = 2; break; }
-                __builtin_amdgcn_s_sleep(4);
+        if (made_seen <= k) {
+            if (tid == 0) {
+                uint32_t give_up = 0, spins = 0, made = 0;
+                for (;;) {
+                    made = duo_load_acquire(flags);
+                    if (made > k) break;
+                    if ((spins & 255u) == 255u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { give_up = 1; break; }
+                    if (++spins > DuoCfg::kSpinLimit) { give_up = 2; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                duo_acquire_fence();
+                misc[6] = give_up; misc[7] = made;
             }
-            misc[6] = give_up;
-        }
-        __syncthreads();
-        if (misc[6] != 0) {
-            if (tid == 0) { duo_store_release(flags + 32, DuoCfg::kAbort); if (misc[6] == 2) atomicMax(status, kErrStream); }
-            return;
+            __syncthreads();
+            if (misc[6] != 0) {
+                if (tid == 0) { duo_store_release(flags + 32, DuoCfg::kAbort); if (misc[6] == 2) atomicMax(status, kErrStream); }
+                return;
+            }
+            made_seen = misc[7];
+            have_next = false;
         }
         const uint32_t* const rec = ring_g + (size_t)(k % DuoCfg::SLOTS) * DuoCfg::REC_WORDS;
-        const uint32_t sp = __builtin_nontemporal_load(rec + 0), op = __builtin_nontemporal_load(rec + 1), ng = __builtin_nontemporal_load(rec + 2);
-        const uint32_t next_op = __builtin_nontemporal_load(rec + 3), flg = __builtin_nontemporal_load(rec + 4), next_sp = __builtin_nontemporal_load(rec + 5);
-        if (flg & DuoCfg::kError) return;                                              // (the PARSE workgroup has reported it)
-        // this thread's pair words and group output offsets: on their way from L2 while the stream is staged
-        uint32_t pw_g[2] = {0, 0}, go_g[2] = {0, 0};
+        // the record's header, this thread's pair words and group output offsets: loaded during the previous chunk when the record
+        // was already there (the PARSE side runs up to four chunks ahead), else now
+        if (!have_next) {
 #pragma unroll
-        for (uint32_t rep = 0; rep < 2; ++rep) {
-            const uint32_t gi = tid + rep * C::T;
-            if (gi < ng * 4u) { pw_g[rep] = rec[DuoCfg::HDR + gi]; go_g[rep] = rec[DuoCfg::HDR + 4u * C::MAXG + (gi >> 2)]; }
+            for (uint32_t q = 0; q < 6; ++q) hdr_n[q] = __builtin_nontemporal_load(rec + q);
+#pragma unroll
+            for (uint32_t rep = 0; rep < 2; ++rep) {
+                const uint32_t gi = tid + rep * C::T;
+                pw_n[rep] = rec[DuoCfg::HDR + gi];
+                go_n[rep] = rec[DuoCfg::HDR + 4u * C::MAXG + (gi >> 2)];
+            }
         }
+        const uint32_t sp = hdr_n[0], op = hdr_n[1], ng = hdr_n[2], next_op = hdr_n[3], flg = hdr_n[4], next_sp = hdr_n[5];
+        const uint32_t pw_g[2] = {pw_n[0], pw_n[1]}, go_g[2] = {go_n[0], go_n[1]};
+        have_next = false;
+        if (flg & DuoCfg::kError) return;                                              // (the PARSE workgroup has reported it)
         const bool last_chunk = (flg & DuoCfg::kLast) != 0u;
         const uint32_t image_len = next_op - op;
         const uint32_t avail = in_len - sp;
@@ -383,7 +475,20 @@ __device__ __forceinline__ void duo_copy(const uint8_t* __restrict__ in, uint32_
             if (tid == 0) { atomicMax(status, (int32_t)misc[4]); duo_store_release(flags + 32, DuoCfg::kAbort); }
             return;
         }
-        if (tid == 0) duo_store_release(flags + 32, k);                              // the record's slot is free
+        // the record's slot is free (every thread holds what it needed from it in registers: the barrier above waited for the loads)
+        if (tid == 0) __hip_atomic_store(flags + 32, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!last_chunk && made_seen > k) {                                          // the next record is there already: fetch it now
+            const uint32_t* const rn = ring_g + (size_t)(k % DuoCfg::SLOTS) * DuoCfg::REC_WORDS;
+#pragma unroll
+            for (uint32_t q = 0; q < 6; ++q) hdr_n[q] = __builtin_nontemporal_load(rn + q);
+#pragma unroll
+            for (uint32_t rep = 0; rep < 2; ++rep) {
+                const uint32_t gi = tid + rep * C::T;
+                pw_n[rep] = rn[DuoCfg::HDR + gi];
+                go_n[rep] = rn[DuoCfg::HDR + 4u * C::MAXG + (gi >> 2)];
+            }
+            have_next = true;
+        }
         typedef __attribute__((address_space(3))) uint16_t lds_u16;
         lds_u16* const le = (lds_u16*)(lds + DuoCopyLds::ent);
         lds_u16* const wl = (lds_u16*)(lds + DuoCopyLds::plist) + 768u * wid;
@@ -494,13 +599,16 @@ __device__ __forceinline__ void duo_copy(const uint8_t* __restrict__ in, uint32_
     flush_image();
 }
 
+// NP PARSE workgroups and one COPY workgroup per block, all on one XCD: workgroup w -> (xcd = w % 8, slot = w / 8), role = slot % (NP + 1),
+// block = (slot / (NP + 1)) * 8 + xcd; the COPY workgroup (role NP) is dispatched last.
+template <uint32_t NP>
 __global__ __launch_bounds__(1024) void dec_duo_kernel(const uint8_t* __restrict__ container, const FrameInfo* __restrict__ frames, uint32_t n_blocks,
                                                        uint8_t* __restrict__ outbuf, int32_t* __restrict__ status,
                                                        uint32_t* __restrict__ ring_g, uint32_t* __restrict__ flags_g)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t w = blockIdx.x, xcd = w & 7u, slot = w >> 3;
-    const uint32_t role = slot & 1u, b = (slot >> 1) * 8u + xcd;
+    const uint32_t role = slot % (NP + 1u), b = (slot / (NP + 1u)) * 8u + xcd;
     if (b >= n_blocks) return;
     const FrameInfo f = frames[b];
     // (the frame descriptor may come from an untrusted container through tsqa_decode_blocks_async: bounds first)
@@ -510,7 +618,7 @@ __global__ __launch_bounds__(1024) void dec_duo_kernel(const uint8_t* __restrict
     }
     uint32_t* const ring_b = ring_g + (size_t)b * DuoCfg::SLOTS * DuoCfg::REC_WORDS;
     uint32_t* const flags = flags_g + (size_t)b * DuoCfg::FLAG_STRIDE;
-    if (role == 0) duo_parse(container + f.stream_at, f.stream_len, f.out_len, f.ext, ring_b, flags, status, lds);
+    if (role < NP) duo_parse<NP>(container + f.stream_at, f.stream_len, f.out_len, f.ext, role, ring_b, flags, status, lds);
     else duo_copy(container + f.stream_at, f.stream_len, f.out_len, f.ext, outbuf + f.out_at, ring_b, flags, status, lds);
 }
 

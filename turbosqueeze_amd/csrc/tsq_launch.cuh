@@ -120,16 +120,20 @@ inline int launch_decode_kernels(tsqa_ctx* c, const uint8_t* container, const Fr
 #endif
     // Few blocks (at most half as many as CUs: every GPU of a multi-GPU job on enwik9): two workgroups per block, one for each of
     // the block's two serial chains (tsq_dec_duo.cuh).
-    if (v == 3 || (v == 0 && 2u * n_blocks <= (uint32_t)c->n_cus)) {
+    // Few blocks (every GPU of a multi-GPU job on enwik9): several workgroups per block on different CUs of one XCD -- the block's
+    // copy chain on one, its parse on one (at most half as many blocks as CUs) or two (at most a third) (tsq_dec_duo.cuh).
+    const bool trio = v == 5 || ((v == 0 || v == 3) && 3u * n_blocks <= (uint32_t)c->n_cus);
+    if (trio || v == 3 || v == 6 || (v == 0 && 2u * n_blocks <= (uint32_t)c->n_cus)) {
         static std::atomic<uint64_t> duo_devices{0};
-        const void* const fns[1] = {reinterpret_cast<const void*>(dec_duo_kernel)};
+        const void* const fns[2] = {reinterpret_cast<const void*>(dec_duo_kernel<1>), reinterpret_cast<const void*>(dec_duo_kernel<2>)};
         const uint32_t lds_bytes = DuoCopyLds::total > SymLds::total ? DuoCopyLds::total : SymLds::total;
-        const uint32_t bytes[1] = {lds_bytes};
+        const uint32_t bytes[2] = {lds_bytes, lds_bytes};
         if (int rc = raise_lds_limit(c, duo_devices, fns, bytes)) return rc;
         if (int rc = c->reserve_duo(n_blocks)) return rc;
         if (hipMemsetAsync(c->duo_flags, 0, (size_t)n_blocks * DuoCfg::FLAG_STRIDE * sizeof(uint32_t), s) != hipSuccess) { c->set_error("hipMemsetAsync failed"); return TSQA_ERR_HIP; }
-        const uint32_t grid = 16u * ((n_blocks + 7u) / 8u);
-        hipLaunchKernelGGL(dec_duo_kernel, dim3(grid), dim3(SymCfg::T), lds_bytes, s, container, frames, n_blocks, out, status, c->duo_ring, c->duo_flags);
+        const uint32_t groups = (n_blocks + 7u) / 8u;
+        if (trio && v != 6) hipLaunchKernelGGL(dec_duo_kernel<2>, dim3(24u * groups), dim3(SymCfg::T), lds_bytes, s, container, frames, n_blocks, out, status, c->duo_ring, c->duo_flags);
+        else hipLaunchKernelGGL(dec_duo_kernel<1>, dim3(16u * groups), dim3(SymCfg::T), lds_bytes, s, container, frames, n_blocks, out, status, c->duo_ring, c->duo_flags);
         return 0;
     }
     // one workgroup per block at any block count: with more blocks than CUs the blocks simply queue (the decoder needs its 150 KB
