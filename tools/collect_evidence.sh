@@ -10,9 +10,31 @@ mkdir -p $OUT
 (timeout 600 python bench.py --steps 10 --warmup 3 2>&1 | tail -1) > $OUT/bench.json
 bash tools/profile_round.sh $TAG > $OUT/profile_round.log 2>&1
 python tools/phase_stats.py > $OUT/phase_stats.txt 2>&1
+python tools/traffic_experiment.py > $OUT/traffic_experiment.jsonl 2>/dev/null
+(cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+ for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --kernel-trace --pmc $c -d $OUT/traffic_$c -o t --output-format csv -- python tools/traffic_experiment.py > /dev/null 2>&1; done
+ python - <<PY
+import csv, glob, collections, json
+out = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    rows = []
+    for fn in glob.glob("$OUT/traffic_%s/**/*counter_collection.csv" % c, recursive=True):
+        for r in csv.DictReader(open(fn)):
+            if "enc_stage_kernel" in r["Kernel_Name"]:
+                rows.append((int(r["Grid_Size"]) // int(r["Workgroup_Size"]), float(r["Counter_Value"])))
+    agg = collections.defaultdict(list)
+    for nb, v in rows:
+        agg[nb].append(v)
+    out[c] = {str(nb): sum(v) / len(v) for nb, v in sorted(agg.items())}
+json.dump(out, open("$OUT/traffic_experiment_pmc.json", "w"), indent=1)
+print(json.dumps(out))
+PY
+) > $OUT/traffic_experiment_pmc.log 2>&1
+timeout 300 python tools/quick_check.py > $OUT/quick_check.txt 2>&1
 for n in 1073741824 4294967296; do timeout 300 python tools/config5_sweep.py $n 1 2>/dev/null; done > $OUT/config5.jsonl
 timeout 300 python tools/config5_sweep.py 1342177280 0 0 text 2>/dev/null >> $OUT/config5.jsonl
 for args in "--synthetic 1000000000 --reps 5 --no-ext" "--synthetic 1000000000 --reps 5" "--synthetic 4000000000 --reps 3"; do timeout 300 tools/tsq_cli b $args 2>/dev/null | tail -1; done > $OUT/cli_host_buffers.json
 tools/micro/lds_unaligned > $OUT/lds_access_costs.txt 2>&1
-TSQ_BENCH_BACKEND=gloo TSQ_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_2ranks_1gpu.json
+TSQ_BENCH_BACKEND=gloo TSQ_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --steps 5 --warmup 2 --no-weak 2>/dev/null | tail -1 > $OUT/bench_2ranks_1gpu.json
+(TSQ_AMD_DEBUG=1 timeout 200 tools/tsq_cli b --synthetic 1000000000 --reps 2 --no-ext 2>&1 | tail -45) > $OUT/cli_timeline.txt
 ls -la $OUT

@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAMES = {0: "(empty: timer cost)", 1: "P wait+loads+prologue", 2: "P orbit+check", 3: "P account", 4: "P resolve", 5: "P flush", 6: "P publish", 7: "P whole segment loop (non-plain tiles)", 8: "P resolve: candidate (twins, LDS words)", 9: "P resolve: decision + outcome", 17: "P after account: masks, tile-end test", 18: "P loop back edge after a hazard",
+NAMES = {0: "(empty: timer cost)", 1: "W wait+loads+prologue", 2: "W orbit+check", 3: "W masks, last match, tile-end test", 4: "W hazard: candidate (twins, LDS words)", 5: "W hazard: decide + event (+ answer)", 6: "W tile end: SEG event", 7: "W visited mask + publish",
          10: "M wait scan + record loads", 11: "M wait parser + commit", 12: "M table gather", 13: "M candidate bytes + prefix", 14: "M classify + write + publish"}
 
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
@@ -38,7 +38,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     sys.exit(0)
 
 rows = []
-for k in [int(x) for x in os.environ.get('TSQ_REGIONS', '0 1 2 3 4 5 6 7 8 9 10 11 12 13 14').split()]:
+for k in [int(x) for x in os.environ.get('TSQ_REGIONS', '0 1 2 3 4 5 6 7 10 11 12 13 14').split()]:
     out = subprocess.run([sys.executable, __file__, "--one", str(k)] + sys.argv[1:], capture_output=True, text=True, timeout=300)
     line = [l for l in out.stdout.splitlines() if l and l[0].isdigit()]
     if not line:

@@ -664,6 +664,8 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
         const uint32_t base = t << 6;
         uint64_t vall = 0;
         if (v < base + 64u) {
+            REG_BEGIN(0); REG_END(0);
+            REG_BEGIN(1);
             // (the serial stage polls without sleeping: a wake-up from s_sleep costs it up to 64 cycles per hand-off)
             const uint32_t orbit_word = (t & 1u) ? kCtlOrbitOdd : 4u;
             if (!stage_ready(ctl, orbit_word, t + 1u)) {
@@ -696,7 +698,9 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
             const uint32_t cand0 = lane_word & 0xFFFFFFu;
 
             uint32_t L = v - base;
+            REG_END(1);
             for (;;) {
+                REG_BEGIN(2);
                 const uint32_t L0 = L;                                           // < 64
                 // the orbit from L0: halts on a hard lane or past the tile (nothing at all if L0 itself is hard)
                 const uint32_t o_lo = rdlane(orb_lo, L0), o_hi = rdlane(orb_hi, L0), o_nx = rdlane(nx, L0);
@@ -729,13 +733,17 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                     TSQ_CNT(23, trunc);
                 }
                 TSQ_CNT(24, 1);
+                REG_END(2);
+                REG_BEGIN(3);
                 {
                     const uint64_t M = V & certain_m;
                     last_m = s_sel(s_nz64(M), base + s_msb64(M | 1ull), last_m);
                 }
                 Vacc |= V;
                 vall |= V;
-                if (L >= 64u) { v = base + L; break; }
+                if (L >= 64u) { v = base + L; REG_END(3); break; }
+                REG_END(3);
+                REG_BEGIN(4);
                 TSQ_CNT(26, 1); TSQ_CNT(27, ((hard >> L) & 1ull) ? 1 : 0);
                 // ---- one hazard lane (hard, or with a visited twin): its candidate and common prefix
                 const uint32_t i = base + L;
@@ -780,6 +788,8 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                     }
                 }
                 vall |= 1ull << L;
+                REG_END(4);
+                REG_BEGIN(5);
                 // The lane decides like a certain lane when no pair origin the reference could use here lies closer to the candidate than
                 // the match is long (tsq_encode.cpp:100,139-145: offset = origin - candidate must reach 4 and the match length): every
                 // such origin -- the one of the scan-time test and the one after the pending literal -- is at or behind the start of the
@@ -812,20 +822,25 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                     last_m = s_sel(s_ge(v - i, 4u), i, last_m);
                 }
                 L = v - base;
+                REG_END(5);
                 if (L >= 64u || done != 0u) break;
             }
+            REG_BEGIN(6);
             if (Vacc != 0ull) ev_push(kEvSeg, base, (uint32_t)Vacc, (uint32_t)(Vacc >> 32));
+            REG_END(6);
         }
         // ---- hand the tile's visited mask to MATCH (it commits the table) and move on
+        REG_BEGIN(7);
         {
             const uint32_t slot = 16u + 2u * (t & 7u);
             if (lane < 2u) __hip_atomic_store(&ctl[slot + lane], lane ? (uint32_t)(vall >> 32) : (uint32_t)vall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         stage_publish(ctl, 5, t + 1u, lane);
         vall_p2 = vall_p1; vall_p1 = vall;
+        REG_END(7);
     }
 #ifdef TSQ_STATS
-    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[8] = st_[8]; g_enc_stats[9] = st_[9]; g_enc_stats[10] = TSQ_TOTAL(); g_enc_stats[15] = st_[15]; for (int q = 23; q < 28; ++q) g_enc_stats[q] = st_[q]; g_enc_stats[29] = st_[17]; g_enc_stats[30] = st_[18]; g_enc_stats[31] = st_[19]; g_enc_stats[20] = st_[20]; g_enc_stats[40] = st_[10]; }
+    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[8] = st_[8]; g_enc_stats[9] = st_[9]; g_enc_stats[10] = TSQ_TOTAL(); g_enc_stats[11] = st_[11]; g_enc_stats[12] = st_[12]; g_enc_stats[15] = st_[15]; for (int q = 23; q < 28; ++q) g_enc_stats[q] = st_[q]; g_enc_stats[29] = st_[17]; g_enc_stats[30] = st_[18]; g_enc_stats[31] = st_[19]; g_enc_stats[20] = st_[20]; g_enc_stats[40] = st_[10]; }
 #endif
     __hip_atomic_store(&ctl[6], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     ev_push(kEvEnd, 0u, 0u, 0u);
