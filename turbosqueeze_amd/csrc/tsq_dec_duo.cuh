@@ -610,6 +610,17 @@ __global__ __launch_bounds__(1024) void dec_duo_kernel(const uint8_t* __restrict
     const uint32_t w = blockIdx.x, xcd = w & 7u, slot = w >> 3;
     const uint32_t role = slot % (NP + 1u), b = (slot / (NP + 1u)) * 8u + xcd;
     if (b >= n_blocks) return;
+    // An error reported before this launch (the frame walk refused the container: the descriptors are not even written) or by
+    // another block: leave, all threads together.  (A block's workgroups may read different values while another block is failing;
+    // every wait inside also watches the status word, so none is left waiting for a partner that left here.)
+    {
+        uint32_t* const seen = reinterpret_cast<uint32_t*>(lds);
+        if (threadIdx.x == 0) seen[0] = (uint32_t)__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const uint32_t st = seen[0];
+        __syncthreads();
+        if (st != 0u) return;
+    }
     const FrameInfo f = frames[b];
     // (the frame descriptor may come from an untrusted container through tsqa_decode_blocks_async: bounds first)
     if (f.stream_len < 3u || f.stream_len > kSlotSize || f.out_len > kBlockSize) {

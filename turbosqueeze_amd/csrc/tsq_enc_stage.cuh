@@ -1,26 +1,35 @@
-// tsq_enc_stage.cuh -- five-wave staged block encoder for gfx950 (kernel variant 0).
+// tsq_enc_stage.cuh -- staged block encoder for gfx950: eleven wavefronts per block (kernel variant 0).
 //
 // A single wavefront issues about one instruction every five cycles, and the greedy parse of a block is
 // serial (tsq_encode.cpp:72-187: the position table is a function of the parse).  So the block's work
-// is cut into stages, one wavefront each, that stream 64-position tiles through records in LDS:
+// is cut into stages that stream 64-position tiles through records in LDS; the serial stage is kept as
+// small as it can be and everything else is spread over as many wavefronts as it takes to keep up with it:
 //
-//   wave 0  SCAN     input words, hashes and the same-hash ("twin") masks of every tile -- everything
-//                    that does not depend on the parse; runs ahead as far as the record ring allows.
-//   wave 1  MATCH    the position table: commits the visited positions of tile t-3 (handed back by the
-//                    parser), gathers the candidates of tile t, their bytes, the common prefixes, and
-//                    classifies the lanes (certain match / certain literal / hazard).
-//   wave 2  ORBIT    the visited set from every possible entry lane of the tile, by pointer doubling.
-//   wave 3  PARSER   the serial part: picks the orbit of the actual entry lane, checks the twins it
-//                    visited, resolves hazards with exact scalar code, keeps the pair state.
-//   wave 4  BUILDER  symbol records and stream layout (tsq_enc_builder.cuh: stream_builder).
+//   HASH     input words (next tile prefetched), hashes, the "owner image" (one byte per folded hash bucket:
+//            which lane of the last three tiles wrote it last) -- a filter for equal hashes.
+//   TWINS    the exact same-hash ("twin") masks of every lane against the earlier lanes of its tile and the
+//            three tiles before: inherited from the bucket owner's own masks when the owner has the lane's
+//            hash (no search), settled with ballots on a fold collision.
+//   MATCH x2 (even / odd tiles) the candidates: gather from the position table, patch with the visited twins
+//            of tile t-3 (mask test), candidate bytes from the input window ring in LDS, common prefix,
+//            lane classes (certain match / certain literal / hazard).
+//   ORBIT x2 (even / odd tiles) the visited set from every possible entry lane of the tile, by pointer doubling;
+//            first the late classification of lanes whose only twins are in tile t-2.
+//   WALK     THE serial stage: picks the orbit of the actual entry lane, checks the twins it visited, finds a
+//            hazard lane's candidate; decides it on the spot when no pair origin can matter, else asks ACCOUNT.
+//   ACCOUNT  the symbol state (count, pair origin, pending literal) in O(1) per tile from WALK's masks, the exact
+//            scalar decision of the hazards WALK could not decide, the items for the builder.
+//   COMMIT   the position table's writer: the visited positions of a tile, as soon as WALK has published them.
+//   BUILDER  symbol records from the items (tsq_enc_builder.cuh: stream_builder).
+//   EMIT     stream layout, 64 symbols at a time (tsq_enc_builder.cuh: stream_emitter).
 //
-// Table lag.  MATCH gathers tile t from a table that holds exactly the visits of tiles <= t-3 (it does
-// the commits itself, in program order), so parser and MATCH overlap over two tiles.  What the table
-// cannot know -- a visited position of tiles t-2, t-1 or an earlier lane of t with the same hash -- is a
-// twin: SCAN finds all of them exactly (byte-per-bucket owner image in LDS, folded to 16 bits, with
-// exact hash comparison by ballot), and the parser takes the most recent VISITED twin as the
-// candidate, which is what the reference's table would hold (tsq_encode.cpp:76-79), or keeps the
-// gathered candidate when no twin was visited.
+// Table lag.  MATCH gathers tile t from a table that holds the visits of tiles <= t-4 (COMMIT publishes how far it
+// is) and patches in the visits of tile t-3 from TWINS' masks, so WALK and MATCH overlap over two tiles.  What the
+// table cannot know -- a visited position of tiles t-2, t-1 or an earlier lane of t with the same hash -- is a
+// twin: TWINS finds all of them exactly, and WALK takes the most recent VISITED twin as the candidate, which is
+// what the reference's table would hold (tsq_encode.cpp:76-79), or keeps the gathered candidate when no twin
+// was visited.  The output therefore does not depend on how the wavefronts interleave (make jitter: a stress
+// build that delays every hand-off pseudo-randomly; tests/test_gpu_parity.py::test_encoder_handoffs_under_jitter).
 #pragma once
 #ifndef TSQ_LATE_FIX
 #define TSQ_LATE_FIX 1
@@ -57,12 +66,14 @@ struct StageCfg {
     static constexpr uint32_t total = off_win + WIN + 32;
     static constexpr uint32_t total_lean = off_win;                            // without the window: two blocks fit one CU
 };
-// ctl words: 0 queue head, 1 queue tail, 2 tiles scanned, 3 tiles matched, 4 tiles with orbits, 5 tiles parsed,
-//            6 stop, 16 + 2*(t&7): visited mask of tile t (lo, hi)
+// ctl words: 0 queue head, 1 queue tail, 2 tiles with twin masks, 3 / 35 even / odd tiles matched, 4 / 15 even / odd tiles with orbits,
+//            5 tiles walked, 6 stop, 7..9 BUILDER/EMIT (tsq_enc_builder.cuh), 10..14 WALK/ACCOUNT events, 33 tiles committed, 34 tiles hashed,
+//            16 + 2*(t&7): visited mask of tile t (lo, hi)
 // record: header words 0,1 = lanes that have an earlier twin inside the tile
 //         per-lane arrays: 0 hash  1,2 twins in this tile (earlier lanes)  3,4 twins in tile t-1  5,6 twins in tile t-2
-//                          7 spanword  8 candidate | nibble << 24  9 orbit halt  10,11 orbit mask
-// spanword: natural span (bits 0..7) | hard (8) | has a twin (9) | certain match (10) | near twin (11) | common prefix (16..23)
+//                          7 spanword  8 candidate | nibble << 24  9 orbit halt  10,11 orbit mask  12,13 twins in tile t-3
+//                          14 owner word (HASH -> TWINS)
+// spanword: natural span (bits 0..7) | hard (8) | has a twin (9) | certain match (10) | near twin (11) | twins of t-2 settled (12) | common prefix (16..23)
 enum : uint32_t { kAH = 0, kATin = 1, kATp1 = 3, kATp2 = 5, kASpan = 7, kALane = 8, kANx = 9, kAOrb = 10, kATp3 = 12, kAOwn = 14 };
 // events between WALK and ACCOUNT, and their ctl words (10 events produced, 11 consumed, 12 queries answered, 13 the answer,
 // 14 the tile ACCOUNT works on: the tiles before it are accounted)
