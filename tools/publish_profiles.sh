@@ -1,0 +1,23 @@
+#!/bin/bash
+# Copies what is to be judged from gpurun_out/$TAG (scratch, written on the GPU box by tools/collect_evidence.sh and
+# tools/sq_counters.sh) into profiles/ (tracked).  Usage: bash tools/publish_profiles.sh r03
+set -eu
+TAG=${1:?tag}
+S=gpurun_out/$TAG
+cp $S/bench.json profiles/${TAG}_bench.json
+cp $S/kernel_stats.csv profiles/${TAG}_rocprofv3_kernel_stats.csv
+tail -1 $S/stats_bench.log > profiles/${TAG}_bench_under_rocprof.json
+cp $S/pmc_summary.json profiles/${TAG}_pmc_fetch_write.json
+cp $S/phase_stats.txt profiles/${TAG}_phase_stats.txt
+cp $S/config5.jsonl profiles/${TAG}_config5.jsonl
+cp $S/cli_host_buffers.json profiles/${TAG}_cli_host_buffers.json
+cp $S/cli_timeline.txt profiles/${TAG}_cli_timeline.txt
+cp $S/bench_2ranks_1gpu.json profiles/${TAG}_bench_2ranks_1gpu.json
+cp $S/pytest_gpu.log profiles/${TAG}_pytest_gpu.log
+cp $S/gpu_box_host.txt profiles/${TAG}_gpu_box_host.txt
+cp $S/traffic_experiment.jsonl profiles/${TAG}_traffic_experiment.jsonl
+cp $S/traffic_experiment_pmc.json profiles/${TAG}_traffic_experiment_pmc.json
+cp $S/quick_check.txt profiles/${TAG}_quick_check.txt
+[ -f $S/sq_counters.txt ] && cp $S/sq_counters.txt profiles/${TAG}_sq_counters.txt
+[ -f $S/regions.txt ] && cp $S/regions.txt profiles/${TAG}_walk_regions.txt
+ls -la profiles/${TAG}_*
