@@ -29,7 +29,7 @@ codec.set_variant(int(os.environ.get("ENC_VARIANT", "0")), int(os.environ.get("D
 blob = codec.compress(src, ext)
 back = codec.decompress(blob)
 assert torch.equal(back, src)
-enc = (C.c_ulonglong * 64)()
+enc = (C.c_ulonglong * 128)()
 dec = (C.c_ulonglong * 16)()
 L.tsqa_debug_stats(enc, dec)
 e = list(enc); d = list(dec)
@@ -42,7 +42,7 @@ print("  MATCH   total=%.0f waited(scan)=%.0f waited(parser)=%.0f busy=%.0f" % (
 print("          length-extension rounds per tile=%.2f (from the window ring %.2f), tiles classified twice (even wave)=%.3f" % (e[36] / T, e[35] / T, e[50] / T))
 print("  COMMIT  total=%.0f waited=%.0f busy=%.0f" % (e[46] / T, e[45] / T, (e[46] - e[45]) / T))
 print("  ORBIT   total=%.0f waited=%.0f busy=%.0f" % (e[7] / T, e[6] / T, (e[7] - e[6]) / T))
-print("  lag loop (even tiles): WALK publishes tile t-3 -> MATCH publishes tile t: %.0f cycles; -> ORBIT publishes tile t: %.0f cycles" % (e[51] / max(e[52], 1), e[53] / max(e[54], 1)))
+print("  lag loop (even tiles): WALK publishes tile t-3 -> MATCH publishes tile t: %.0f cycles -> ORBIT publishes tile t: %.0f cycles" % (e[51] / max(e[52], 1), e[53] / max(e[54], 1)))
 print("  WALK    total=%.0f waited(orbit)=%.0f waited(events)=%.0f waited(answers)=%.0f busy=%.0f  queries per tile=%.3f" % (e[10] / T, e[8] / T, e[9] / T, e[40] / T, (e[10] - e[8] - e[9] - e[40]) / T, e[20] / T))
 print("  ACCOUNT total=%.0f waited(events)=%.0f waited(queue)=%.0f busy=%.0f  tiles with events=%.3f  local decisions that disagree=%d" % (e[43] / T, e[41] / T, e[42] / T, (e[43] - e[41] - e[42]) / T, e[44] / T, e[22]))
 

@@ -638,7 +638,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
     const uint32_t tail_from = uniform(n >= 5u ? n - 5u : 0u);
 
     uint32_t ev_head = 0, ev_tail_seen = 0, n_query = 0;
-    uint32_t v = 1, done = 0, t_done = 0;
+    uint32_t v = 1, done = 0;
     uint32_t last_m = 0;                 // where the most recent match symbol starts: no pair origin lies before it
     uint64_t vall_p1 = 0, vall_p2 = 0;   // visited lanes of the two previous tiles
 #ifdef TSQ_STATS
@@ -707,6 +707,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
             const uint64_t hard = __ballot((spanword & 0x100u) != 0u);
             const uint64_t near_m = __ballot((spanword & 0x800u) != 0u);
             const uint64_t certain_m = __ballot((spanword & 0x400u) != 0u);
+            uint64_t Vacc = 0;                   // visited lanes not yet handed to ACCOUNT
             // a twin visited in the two previous tiles: fixed for the whole tile (kept per lane, it joins the in-tile test)
             const uint32_t prev_hit = (tp1_lo & (uint32_t)vall_p1) | (tp1_hi & (uint32_t)(vall_p1 >> 32)) |
                                       (tp2_lo & (uint32_t)vall_p2) | (tp2_hi & (uint32_t)(vall_p2 >> 32));
@@ -755,6 +756,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                     const uint64_t M = V & certain_m;
                     last_m = s_sel(s_nz64(M), base + s_msb64(M | 1ull), last_m);
                 }
+                Vacc |= V;
                 vall |= V;
                 if (L >= 64u) { v = base + L; REG_END(3); break; }
                 REG_END(3);
@@ -813,20 +815,14 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                 const uint32_t need = k < 4u ? 4u : k;
                 const uint32_t local = s_ge(last_m, cand + need) & s_lt(i, tail_from) & s_lt(i - cand, 0xFF00u);
                 if (local) {
-                    // the lane's class goes straight into the tile's record, where ACCOUNT will find it when the tile is finished
+                    ev_push(kEvHaz, i, cand, k | (twin_cand << 8) | (1u << 9));
                     const uint32_t m = length_nibble(need);
                     const uint32_t is_m = s_ge(k, 4u);
-                    const uint32_t sp = s_sel(is_m, nibble_span(m), 1u);
-                    if (lane == L) {
-                        arr[kASpan * 64] = (spanword & ~0x4FFu) | sp | (is_m << 10);
-                        arr[kALane * 64] = cand | (m << 24);
-                    }
                     v = s_sel(is_m, i + nibble_span(m), i + 1u);
                     last_m = s_sel(is_m, i, last_m);
+                    Vacc |= 1ull << L;
                 } else {
-                    // ACCOUNT gets the lanes of this tile visited so far, then the query
-                    const uint64_t before = vall & ~(1ull << L);
-                    if (before != 0ull) ev_push(kEvSeg, base, (uint32_t)before, (uint32_t)(before >> 32));
+                    if (Vacc != 0ull) { ev_push(kEvSeg, base, (uint32_t)Vacc, (uint32_t)(Vacc >> 32)); Vacc = 0; }
                     ev_push(kEvHaz, i, cand, k | (twin_cand << 8));
                     n_query++;
                     TSQ_CNT(20, 1);
@@ -846,6 +842,9 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                 REG_END(5);
                 if (L >= 64u || done != 0u) break;
             }
+            REG_BEGIN(6);
+            if (Vacc != 0ull) ev_push(kEvSeg, base, (uint32_t)Vacc, (uint32_t)(Vacc >> 32));
+            REG_END(6);
         }
         // ---- hand the tile's visited mask to MATCH (it commits the table) and move on
         REG_BEGIN(7);
@@ -854,18 +853,17 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
             if (lane < 2u) __hip_atomic_store(&ctl[slot + lane], lane ? (uint32_t)(vall >> 32) : (uint32_t)vall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
 #ifdef TSQ_STATS
-        if (lane == 0) ctl[40u + (t & 7u)] = (uint32_t)__builtin_amdgcn_s_memtime();
+        if (lane == 0) ctl[40u + (t & 7u)] = (uint32_t)__builtin_amdgcn_s_memtime();       // (the lag loop is timed from here)
 #endif
         stage_publish(ctl, 5, t + 1u, lane);
         vall_p2 = vall_p1; vall_p1 = vall;
-        t_done = t + 1u;
         REG_END(7);
     }
 #ifdef TSQ_STATS
     if (blockIdx.x == 0 && lane == 0) { g_enc_stats[8] = st_[8]; g_enc_stats[9] = st_[9]; g_enc_stats[10] = TSQ_TOTAL(); g_enc_stats[11] = st_[11]; g_enc_stats[12] = st_[12]; g_enc_stats[15] = st_[15]; for (int q = 23; q < 28; ++q) g_enc_stats[q] = st_[q]; g_enc_stats[29] = st_[17]; g_enc_stats[30] = st_[18]; g_enc_stats[31] = st_[19]; g_enc_stats[20] = st_[20]; g_enc_stats[40] = st_[10]; }
 #endif
     __hip_atomic_store(&ctl[6], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    ev_push(kEvEnd, t_done, 0u, 0u);
+    ev_push(kEvEnd, 0u, 0u, 0u);
 }
 
 // All symbol state lives in uniform 32-bit integers (flags as 0/1, not bool: a bool that crosses a branch
@@ -977,99 +975,16 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
         }
     };
 
-    // ---- the segment's effect on the symbol state, O(1) from its masks.  `dsym` symbols close (matches and
-    //      the literal runs in front of them); the state afterwards hangs on the last match.
-    auto account_seg = [&](uint64_t V) {
-        {
-            const uint32_t fresh = s_nz64(Vt) ^ 1u;
-            e_nsym = s_sel(fresh, nsym, e_nsym); e_origin = s_sel(fresh, origin, e_origin); e_lit_from = s_sel(fresh, lit_from, e_lit_from);
-        }
-        const uint64_t M = V & certain_m, N = V ^ M;
-        const uint32_t L0 = s_lsb64(V);
-        const uint32_t has_m = s_nz64(M);
-        const uint32_t Le = s_msb64(V | 1ull), Lm = s_msb64(M | 1ull);
-        const uint32_t first_isN = (uint32_t)(N >> L0) & 1u;                // L0 is the lowest lane of V
-        uint64_t r = N & (N >> 1); r &= r >> 2; r &= r >> 4; r &= r >> 8;     // a literal run of 16 or more inside
-        const uint32_t run_end = base + s_sel(has_m, s_lsb64(M | (1ull << 63)), Le + 1u);
-        const uint32_t chunk = s_ge(run_end - lit_from, 16u) & first_isN;     // the entry run completes a 16-byte chunk
-        if (__builtin_expect(s_nz64(r) | chunk, 0)) { TSQ_CNT(28, 1); replay_segment(V); }
-        else {
-            const uint32_t e_pos = base + L0, lm_pos = base + Lm, endm = lm_pos + rdlane(span_nat, Lm);
-            const uint32_t last_m = s_eq(Le, Lm) & has_m;
-            const uint32_t pre = s_lt(lit_from, e_pos) & (first_isN ^ 1u);      // a pending literal closes in front of an entry match
-            const uint32_t dsym = (uint32_t)__builtin_popcountll(M) + (uint32_t)__builtin_popcountll(M & (N << 1)) + pre;
-            const uint32_t nsym_n = nsym + s_sel(has_m, dsym, 0u);
-            const uint32_t origin_n = s_sel(has_m, s_sel(nsym_n & 1u, lm_pos, endm), origin);
-            const uint32_t new_run = s_sel(has_m, last_m ^ 1u, am);              // a literal run starts inside / at the entry of the segment
-            run0 = s_sel(new_run, s_sel(has_m, endm, e_pos), run0);
-            origin_r0 = s_sel(new_run, origin_n, origin_r0);
-            odd_r0 = s_sel(new_run, nsym_n & 1u, odd_r0);
-            lit_from = s_sel(has_m, endm, lit_from);
-            am = last_m;
-            nsym = nsym_n;
-            origin = origin_n;
-        }
-        Vt |= V; Mt |= M;
-    };
-    // ACCOUNT follows two streams from WALK: the TILES -- a finished tile's visited lanes are in the slot WALK publishes for MATCH and
-    // COMMIT anyway, and hazard lanes WALK decided itself are already patched into the tile's record -- and the rare EVENTS: a query
-    // (preceded by the lanes of its tile visited so far), and the end.  An event is pushed before its tile is published, so once the
-    // tile counter has been read, an event counter read AFTER it shows every event of the tiles below it.
-    uint32_t t_acc = 0;                  // tiles below this one are accounted
-    uint32_t open = 0;                   // tile t_acc is open: its record is loaded, some of its lanes are accounted (Vdone)
-    uint64_t Vdone = 0, qmask = 0;       // ... and which lanes a query decided (their candidate word is not in the record)
-    uint32_t parsed_seen = 0, ev_head_seen = 0;
-    auto load_tile = [&](uint32_t t) {
-        volatile lds_u32_t* arr = recs + (t % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::ARR + lane;
-        const uint32_t spanword = arr[kASpan * 64];
-        const uint32_t fresh_lw = arr[kALane * 64];
-        lw = ((qmask >> lane) & 1ull) ? lw : fresh_lw;
-        span_nat = spanword & 0xFFu;
-        certain_m = __ballot((spanword & 0x400u) != 0u);
-    };
-    auto open_tile = [&](uint32_t t) {
-        flush_pending();                 // what is pending of the tile before goes to the builder
-        base = t << 6;
-        Vdone = 0; qmask = 0;
-        load_tile(t);
-        // (HASH may reuse the records of the tiles before this one)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __hip_atomic_store(&ctl[kCtlAccounted], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        open = 1;
-        TSQ_CNT(15, 1);
-    };
-    auto finish_tile = [&]() {           // tile t_acc is complete: account what is left of it
-        const uint32_t slot = 16u + 2u * (t_acc & 7u);
-        const uint64_t vall = (uint64_t)uniform(__hip_atomic_load(&ctl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) |
-                              ((uint64_t)uniform(__hip_atomic_load(&ctl[slot + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) << 32);
-        const uint64_t V = vall & ~Vdone;
-        if (V != 0ull) {
-            if (open) load_tile(t_acc);  // (WALK may have patched lanes after the tile was opened by a query)
-            else open_tile(t_acc);
-            account_seg(V);
-        }
-        open = 0; Vdone = 0;
-        t_acc++;
-    };
-
     TSQ_BEGIN();
     for (;;) {
-        if (ev_tail == ev_head_seen && parsed_seen <= t_acc) {
-            parsed_seen = uniform(__hip_atomic_load(&ctl[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            asm volatile("" ::: "memory");
-            ev_head_seen = uniform(__hip_atomic_load(&ctl[kCtlEvHead], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            asm volatile("" ::: "memory");
-        }
-        if (ev_tail == ev_head_seen) {
-            if (parsed_seen > t_acc) { finish_tile(); continue; }
+        if (!stage_ready(ctl, kCtlEvHead, ev_tail + 1u)) {
 #ifdef TSQ_STATS
             const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
 #endif
-            __builtin_amdgcn_s_sleep(1);
+            while (!stage_ready(ctl, kCtlEvHead, ev_tail + 1u)) __builtin_amdgcn_s_sleep(1);
 #ifdef TSQ_STATS
             st_[8] += __builtin_amdgcn_s_memtime() - w0_;
 #endif
-            continue;
         }
         uint32_t kind, ea, eb, ec;
         {
@@ -1079,28 +994,74 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
             ev_tail++;
             __hip_atomic_store(&ctl[kCtlEvTail], ev_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        if (kind == kEvEnd) {
-            while (t_acc < ea) finish_tile();                  // (ea: the tiles WALK went through; all of them are complete)
-            break;
+        if (kind == kEvEnd) break;
+        const uint32_t ev_base = ea & ~63u;
+        if (ev_base != base) {
+            // ---- a new tile: what is pending goes to the builder, then the tile's record
+            flush_pending();
+            base = ev_base;
+            const uint32_t t = base >> 6;
+            volatile lds_u32_t* arr = recs + (t % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::ARR + lane;
+            const uint32_t spanword = arr[kASpan * 64];
+            lw = arr[kALane * 64];
+            span_nat = spanword & 0xFFu;
+            certain_m = __ballot((spanword & 0x400u) != 0u);
+            // (SCAN may reuse the records of the tiles before this one)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __hip_atomic_store(&ctl[kCtlAccounted], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            TSQ_CNT(15, 1);
         }
-        const uint32_t te = ea >> 6;
-        while (t_acc < te) finish_tile();                      // WALK is inside tile te: the tiles before it are complete
-        if (!open) open_tile(te);
-        else if (kind == kEvSeg) load_tile(te);                // (lanes WALK decided since the tile was opened are in the record now)
+        {
+            const uint32_t fresh = s_nz64(Vt) ^ 1u;
+            e_nsym = s_sel(fresh, nsym, e_nsym); e_origin = s_sel(fresh, origin, e_origin); e_lit_from = s_sel(fresh, lit_from, e_lit_from);
+        }
         if (kind == kEvSeg) {
-            // the lanes of this tile visited before the query that follows (cumulative)
-            const uint64_t V = ((uint64_t)eb | ((uint64_t)ec << 32)) & ~Vdone;
-            if (V != 0ull) { account_seg(V); Vdone |= V; }
-        } else {
-            {
-                const uint32_t fresh = s_nz64(Vt) ^ 1u;
-                e_nsym = s_sel(fresh, nsym, e_nsym); e_origin = s_sel(fresh, origin, e_origin); e_lit_from = s_sel(fresh, lit_from, e_lit_from);
+            // ---- the segment's effect on the symbol state, O(1) from its masks.  `dsym` symbols close (matches and
+            //      the literal runs in front of them); the state afterwards hangs on the last match.
+            const uint64_t V = (uint64_t)eb | ((uint64_t)ec << 32);
+            const uint64_t M = V & certain_m, N = V ^ M;
+            const uint32_t L0 = s_lsb64(V);
+            const uint32_t has_m = s_nz64(M);
+            const uint32_t Le = s_msb64(V | 1ull), Lm = s_msb64(M | 1ull);
+            const uint32_t first_isN = (uint32_t)(N >> L0) & 1u;                // L0 is the lowest lane of V
+            uint64_t r = N & (N >> 1); r &= r >> 2; r &= r >> 4; r &= r >> 8;     // a literal run of 16 or more inside
+            const uint32_t run_end = base + s_sel(has_m, s_lsb64(M | (1ull << 63)), Le + 1u);
+            const uint32_t chunk = s_ge(run_end - lit_from, 16u) & first_isN;     // the entry run completes a 16-byte chunk
+            if (__builtin_expect(s_nz64(r) | chunk, 0)) { TSQ_CNT(28, 1); replay_segment(V); }
+            else {
+                const uint32_t e_pos = base + L0, lm_pos = base + Lm, endm = lm_pos + rdlane(span_nat, Lm);
+                const uint32_t last_m = s_eq(Le, Lm) & has_m;
+                const uint32_t pre = s_lt(lit_from, e_pos) & (first_isN ^ 1u);      // a pending literal closes in front of an entry match
+                const uint32_t dsym = (uint32_t)__builtin_popcountll(M) + (uint32_t)__builtin_popcountll(M & (N << 1)) + pre;
+                const uint32_t nsym_n = nsym + s_sel(has_m, dsym, 0u);
+                const uint32_t origin_n = s_sel(has_m, s_sel(nsym_n & 1u, lm_pos, endm), origin);
+                const uint32_t new_run = s_sel(has_m, last_m ^ 1u, am);              // a literal run starts inside / at the entry of the segment
+                run0 = s_sel(new_run, s_sel(has_m, endm, e_pos), run0);
+                origin_r0 = s_sel(new_run, origin_n, origin_r0);
+                odd_r0 = s_sel(new_run, nsym_n & 1u, odd_r0);
+                lit_from = s_sel(has_m, endm, lit_from);
+                am = last_m;
+                nsym = nsym_n;
+                origin = origin_n;
             }
+            Vt |= V; Mt |= M;
+        } else {
             const uint32_t i = ea, cand = eb;
             uint32_t k = ec & 0xFFu;
+            const uint32_t is_query = ((ec >> 9) & 1u) ^ 1u;
             const uint32_t L = i - base;
             const uint64_t bit = 1ull << L;
-            Vdone |= bit; qmask |= bit;
+            if (is_query == 0u) {
+                // ---- a hazard lane WALK has decided: it joins the tile's masks like a certain lane
+                const uint32_t is_m = s_ge(k, 4u);
+                const uint32_t m = length_nibble(k < 4u ? 4u : k);
+                certain_m = s_sel64(is_m, certain_m | bit, certain_m & ~bit);
+                const uint32_t sp = s_sel(is_m, nibble_span(m), 1u);
+                span_nat = lane == L ? sp : span_nat;
+                lw = lane == L ? (cand | (m << 24)) : lw;
+                TSQ_CNT(21, is_m);
+                continue;
+            }
             // ---- exact scalar resolution of one hazard lane (hard, or with a visited twin)
             uint32_t v = i + 1u, done = 0;
             const uint32_t e4 = s_ge(k, 4u);
@@ -1156,10 +1117,12 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
                     v = ni;
                 }
             }
-            __hip_atomic_store(&ctl[kCtlReplyValue], v | (done << 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            TSQ_LDS_RELEASE();
-            n_reply++;
-            __hip_atomic_store(&ctl[kCtlReplies], n_reply, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (is_query) {
+                __hip_atomic_store(&ctl[kCtlReplyValue], v | (done << 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                TSQ_LDS_RELEASE();
+                n_reply++;
+                __hip_atomic_store(&ctl[kCtlReplies], n_reply, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
     }
     flush_pending();
