@@ -222,7 +222,10 @@ void tsqInit(struct TSQCompressionContext *ctx);
  * hold TSQ_OUTPUT_SZ bytes.  As in the reference (tsq_encode.cpp:74,108,126,162; its scheduler hands workers pointers
  * into the caller's contiguous buffer, tsq_threads.cpp:109) the encoder looks up to 128 bytes past
  * inputBlock[inputSize-1]: what is readable there is used (so a loop over the blocks of one buffer gives the
- * reference's bytes), what is not mapped is seen as zeros instead of faulting. */
+ * reference's bytes), what is not mapped is seen as zeros instead of faulting.  The look-ahead is taken with
+ * process_vm_readv(2) on the calling process; where a sandbox refuses that call (EPERM / ENOSYS) every block sees zeros behind
+ * it -- the library says so once on stderr -- and TSQ_AMD_ENCODE_NO_LOOKAHEAD=1 asks for that behaviour explicitly.  Callers that
+ * must not depend on either use tsqa_encode_blocks_async, which takes the look-ahead bytes as part of its input layout. */
 void tsqEncode(struct TSQCompressionContext *ctx, uint8_t *inputBlock, uint8_t *outputBlock,
                uint32_t *outputSize, uint32_t inputSize, uint32_t withExtensions);
 /* turbosqueeze.h:670 -- *outputSize = 0 on an oversize header or a malformed stream. */
