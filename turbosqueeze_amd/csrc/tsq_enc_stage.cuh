@@ -51,12 +51,12 @@ struct StageCfg {
     static constexpr uint32_t ITEM_WORDS = 80;
     static constexpr uint32_t RING = 256;                          // symbol records between BUILDER and EMIT (four batches)
     static constexpr uint32_t R = 8;                              // tile records in flight
-    static constexpr uint32_t OWN_MASK = 0x7FFFu;                 // owner image: hash folded to 15 bits, one byte per bucket (32 KiB)
+    static constexpr uint32_t OWN_MASK = 0x7FFFu;                 // owner image: hash folded to 15 bits
     static constexpr uint32_t WIN = 73728;                        // input window ring: the last 64 KiB of input and then some (a multiple of 64)
     static constexpr uint32_t W16 = 16;                           // word offset of the uint4-per-lane input words
     static constexpr uint32_t ARR = 16 + 256;                     // word offset of the u32-per-lane arrays
-    static constexpr uint32_t REC_WORDS = ARR + 17 * 64;
-    static constexpr uint32_t off_owner = 0;                                   // u8[OWN_MASK + 1]
+    static constexpr uint32_t REC_WORDS = ARR + 15 * 64;
+    static constexpr uint32_t off_owner = 0;                                   // u8[65536]
     static constexpr uint32_t off_queue = OWN_MASK + 1u;                       // u32[Q * ITEM_WORDS]
     static constexpr uint32_t off_ring = off_queue + Q * ITEM_WORDS * 4;       // u32[RING]
     static constexpr uint32_t off_rec = off_ring + RING * 4;                   // u32[R * REC_WORDS]
@@ -74,7 +74,7 @@ struct StageCfg {
 //                          7 spanword  8 candidate | nibble << 24  9 orbit halt  10,11 orbit mask  12,13 twins in tile t-3
 //                          14 owner word (HASH -> TWINS)
 // spanword: natural span (bits 0..7) | hard (8) | has a twin (9) | certain match (10) | near twin (11) | twins of t-2 settled (12) | common prefix (16..23)
-enum : uint32_t { kAH = 0, kATin = 1, kATp1 = 3, kATp2 = 5, kASpan = 7, kALane = 8, kANx = 9, kAOrb = 10, kATp3 = 12, kAOwn = 14, kATp4 = 15 };
+enum : uint32_t { kAH = 0, kATin = 1, kATp1 = 3, kATp2 = 5, kASpan = 7, kALane = 8, kANx = 9, kAOrb = 10, kATp3 = 12, kAOwn = 14 };
 // events between WALK and ACCOUNT, and their ctl words (10 events produced, 11 consumed, 12 queries answered, 13 the answer,
 // 14 the tile ACCOUNT works on: the tiles before it are accounted)
 enum : uint32_t { kEvSeg = 1, kEvHaz = 2, kEvEnd = 3 };
@@ -191,8 +191,10 @@ __device__ __forceinline__ void stage_hash(const uint8_t* src, uint64_t avail, u
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
     const uint32_t n_tiles = (n >> 6) + 3u;            // visits reach at most n + 63
+    uint32_t hf_m1 = 0, hf_m2 = 0, hf_m3 = 0;           // folded hashes of tiles t-1 .. t-3 (per lane)
+    uint32_t id = 1;                                    // (t % 3) + 1: which of the three live tiles an owner tag names
     uint32_t wbase = 0;                                 // (t * 64) % WIN
-    uint32_t parsed_seen = 0, accounted_seen = 0, committed_seen = 0, twinned_seen = 0;
+    uint32_t parsed_seen = 0, accounted_seen = 0, committed_seen = 0;
 #ifdef TSQ_STATS
     unsigned long long st_[32] = {0};
 #endif
@@ -204,20 +206,17 @@ __device__ __forceinline__ void stage_hash(const uint8_t* src, uint64_t avail, u
         if (t + 3u > StageCfg::R && !stage_wait_seen(ctl, 5, t + 3u - StageCfg::R, parsed_seen, 0)) break;
         if (t + 1u > StageCfg::R && !stage_wait_seen(ctl, kCtlAccounted, t + 1u - StageCfg::R, accounted_seen, 0)) break;
         if (t + 1u > StageCfg::R && !stage_wait_seen(ctl, kCtlCommitted, t + 1u - StageCfg::R, committed_seen, 0)) break;
-        // ... and TWINS is done with it: tile q's masks are inherited from the records of tiles q-1 .. q-4, hash word included
-        if (t + 4u > StageCfg::R && !stage_wait_seen(ctl, 2, t + 5u - StageCfg::R, twinned_seen, 0)) break;
         const uint32_t p = (t << 6) + lane;
         const uint4 w16 = w_next;
         w_next = ld128z(src, (uint64_t)p + 64u, avail);    // the next tile's words: this wave's only global access, a full iteration ahead
         const uint32_t h = hash4(w16.x);
         const uint32_t hf = h & StageCfg::OWN_MASK;
-        // The owner image: per folded hash, the last lane that had it and the low two bits of its tile number.  Nothing is ever
-        // retired: an entry is taken for what it says -- a lane one to four tiles back -- and TWINS checks it against that lane's own
-        // hash: a lane that really owns the bucket has this folded hash; the zero the image starts with and entries older than four
-        // tiles name a lane that (but for a 1 : 32 768 coincidence, which is settled exactly like any fold collision) has not.
-        const uint32_t tag = ((t & 3u) << 6) | lane;
+        const uint32_t tag = (id << 6) | lane;          // never 0: the image starts zeroed
         volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
+        // The bucket's owner: the most recent lane of tiles t-1 .. t-3 with this folded hash (tile t-3 has tile t's id; nothing of
+        // tile t is in the image yet).  Then the entries of tile t-3 retire, unless a later tile has taken the bucket over.
         const uint32_t before = owner[hf];
+        if (t >= 3u && ((uint32_t)owner[hf_m3] >> 6) == id) owner[hf_m3] = 0;
         owner[hf] = (uint8_t)tag;
         const uint32_t after = owner[hf];
         {
@@ -231,8 +230,10 @@ __device__ __forceinline__ void stage_hash(const uint8_t* src, uint64_t avail, u
         }
         volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
         arr[kAH * 64] = h;
-        arr[kAOwn * 64] = before | (after != tag ? 0x10000u : 0u);                 // owner before | another lane of the tile took the bucket
+        arr[kAOwn * 64] = before | (id << 8) | (after != tag ? 0x1000u : 0u);     // owner before | this tile's id | another lane of the tile took the bucket
         stage_publish(ctl, kCtlHashed, t + 1u, lane);
+        hf_m3 = hf_m2; hf_m2 = hf_m1; hf_m1 = hf;
+        id = id == 3u ? 1u : id + 1u;
         wbase = wbase + 64u == StageCfg::WIN ? 0u : wbase + 64u;
     }
 #ifdef TSQ_STATS
@@ -245,7 +246,7 @@ __device__ __forceinline__ void stage_twins(uint32_t n, lds_u8_t* lds, uint32_t 
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
     const uint32_t n_tiles = (n >> 6) + 3u;
-    uint32_t h_m1 = 0xFFFFFFFFu, h_m2 = 0xFFFFFFFFu, h_m3 = 0xFFFFFFFFu, h_m4 = 0xFFFFFFFFu;   // hashes of tiles t-1 .. t-4 (per lane)
+    uint32_t h_m1 = 0xFFFFFFFFu, h_m2 = 0xFFFFFFFFu, h_m3 = 0xFFFFFFFFu;   // hashes of tiles t-1 .. t-3 (per lane)
     uint32_t hashed_seen = 0;
 #ifdef TSQ_STATS
     unsigned long long st_[32] = {0};
@@ -254,43 +255,43 @@ __device__ __forceinline__ void stage_twins(uint32_t n, lds_u8_t* lds, uint32_t 
     for (uint32_t t = 0; t < n_tiles; ++t) {
         if (!stage_wait_seen(ctl, kCtlHashed, t + 1u, hashed_seen, 0)) break;
         volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
+        volatile lds_u32_t* rec_m1 = recs + ((t + StageCfg::R - 1u) % StageCfg::R) * StageCfg::REC_WORDS;
+        volatile lds_u32_t* rec_m2 = recs + ((t + StageCfg::R - 2u) % StageCfg::R) * StageCfg::REC_WORDS;
+        volatile lds_u32_t* rec_m3 = recs + ((t + StageCfg::R - 3u) % StageCfg::R) * StageCfg::REC_WORDS;
         volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
         const uint32_t h = arr[kAH * 64];
         const uint32_t own = arr[kAOwn * 64];
         const uint32_t before = own & 0xFFu;
-        // ---- twins in the four previous tiles (t-1, t-2: the parser's business; t-3, t-4: MATCH folds their visited lanes into the
-        // candidates; older tiles are in the table).  If the bucket's owner -- the MOST RECENT lane with this folded hash, d tiles back --
-        // has this lane's hash, this lane's twins are the owner and the owner's own twins (already exact, by induction): no search.
-        // If it has another hash (a fold collision: 256 live entries in 16 K buckets), a twin may hide behind it: settled with ballots.
-        uint64_t twin_p1 = 0, twin_p2 = 0, twin_p3 = 0, twin_p4 = 0;
+        const uint32_t id = (own >> 8) & 3u;
+        const uint32_t id_m1 = id == 1u ? 3u : id - 1u; // the id of tile t-1 (the third one is tile t-2's)
+        // ---- twins in the three previous tiles (t-1, t-2: the parser's business; t-3: MATCH folds its visited lanes into the
+        // candidates; older tiles are in the table).  If the owner's hash is this lane's hash, this lane's twins are the owner and
+        // the owner's own twins (already exact, by induction): no search.  If it is another hash (a fold collision: 192 live
+        // entries in 32 K buckets), a twin may hide behind it: settled with ballots below.
+        uint64_t twin_p1 = 0, twin_p2 = 0, twin_p3 = 0;
         bool unsure = false;
-        const uint32_t d0 = (t - (before >> 6)) & 3u;
-        const uint32_t d = d0 ? d0 : 4u;                                          // how many tiles back the owner says it is
-        const bool live = d <= t;
-        if (__ballot(live) != 0ull) {
+        if (__ballot(before != 0u) != 0ull) {
             const uint32_t q = before & 63u;
-            volatile lds_u32_t* qa = recs + ((t + 2u * StageCfg::R - (live ? d : 1u)) % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::ARR + q;
+            const uint32_t bid = before >> 6;
+            const bool in_p1 = bid == id_m1, in_p3 = bid == id;
+            volatile lds_u32_t* qa = (in_p1 ? rec_m1 : in_p3 ? rec_m3 : rec_m2) + StageCfg::ARR + q;
             const uint32_t hq = qa[kAH * 64];
             const uint64_t q_in = (uint64_t)qa[kATin * 64] | ((uint64_t)qa[(kATin + 1) * 64] << 32);
             const uint64_t q_p1 = (uint64_t)qa[kATp1 * 64] | ((uint64_t)qa[(kATp1 + 1) * 64] << 32);
             const uint64_t q_p2 = (uint64_t)qa[kATp2 * 64] | ((uint64_t)qa[(kATp2 + 1) * 64] << 32);
-            const uint64_t q_p3 = (uint64_t)qa[kATp3 * 64] | ((uint64_t)qa[(kATp3 + 1) * 64] << 32);
-            const bool owns = live && ((hq ^ h) & StageCfg::OWN_MASK) == 0u;         // the named lane has this folded hash: the entry is what it says
-            const bool same = owns && hq == h;
-            unsure = owns && hq != h;
+            const bool same = before != 0u && hq == h;
+            unsure = before != 0u && hq != h;
             const uint64_t chain = q_in | (1ull << q);
             if (same) {
-                // twins k tiles back: none for k < d, the owner and its in-tile twins for k = d, the owner's twins k - d tiles before ITS tile beyond
-                twin_p1 = d == 1u ? chain : 0ull;
-                twin_p2 = d == 2u ? chain : d == 1u ? q_p1 : 0ull;
-                twin_p3 = d == 3u ? chain : d == 2u ? q_p1 : d == 1u ? q_p2 : 0ull;
-                twin_p4 = d == 4u ? chain : d == 3u ? q_p1 : d == 2u ? q_p2 : q_p3;
+                twin_p1 = in_p1 ? chain : 0ull;
+                twin_p2 = in_p1 ? q_p1 : in_p3 ? 0ull : chain;
+                twin_p3 = in_p1 ? q_p2 : in_p3 ? chain : q_p1;
             }
         }
         // twins inside the tile: for each lane the mask of EARLIER lanes with the same hash
         uint64_t twin_in = 0, twins_here = 0;
         {
-            uint64_t shared = __ballot((own & 0x10000u) != 0u);
+            uint64_t shared = __ballot((own & 0x1000u) != 0u);
             while (shared) {
                 TSQ_CNT(22, 1);
                 const uint32_t hl = rdlane(h, lsb64(shared));
@@ -306,9 +307,9 @@ __device__ __forceinline__ void stage_twins(uint32_t n, lds_u8_t* lds, uint32_t 
             while (maybe) {
                 TSQ_CNT(21, 1);
                 const uint32_t hl = rdlane(h, lsb64(maybe));
-                const uint64_t g1 = __ballot(h_m1 == hl), g2 = __ballot(h_m2 == hl), g3 = __ballot(h_m3 == hl), g4 = __ballot(h_m4 == hl);
+                const uint64_t g1 = __ballot(h_m1 == hl), g2 = __ballot(h_m2 == hl), g3 = __ballot(h_m3 == hl);
                 const uint64_t grp_cur = __ballot(h == hl);
-                if (h == hl) { twin_p1 = g1; twin_p2 = g2; twin_p3 = g3; twin_p4 = g4; }
+                if (h == hl) { twin_p1 = g1; twin_p2 = g2; twin_p3 = g3; }
                 maybe &= ~grp_cur;
             }
         }
@@ -317,9 +318,8 @@ __device__ __forceinline__ void stage_twins(uint32_t n, lds_u8_t* lds, uint32_t 
         arr[kATp1 * 64] = (uint32_t)twin_p1;  arr[(kATp1 + 1) * 64] = (uint32_t)(twin_p1 >> 32);
         arr[kATp2 * 64] = (uint32_t)twin_p2;  arr[(kATp2 + 1) * 64] = (uint32_t)(twin_p2 >> 32);
         arr[kATp3 * 64] = (uint32_t)twin_p3;  arr[(kATp3 + 1) * 64] = (uint32_t)(twin_p3 >> 32);
-        arr[kATp4 * 64] = (uint32_t)twin_p4;  arr[(kATp4 + 1) * 64] = (uint32_t)(twin_p4 >> 32);
         stage_publish(ctl, 2, t + 1u, lane);
-        h_m4 = h_m3; h_m3 = h_m2; h_m2 = h_m1; h_m1 = h;
+        h_m3 = h_m2; h_m2 = h_m1; h_m1 = h;
     }
 #ifdef TSQ_STATS
     if (blockIdx.x == 0 && lane == 0) { g_enc_stats[48] = st_[0]; g_enc_stats[49] = TSQ_TOTAL(); g_enc_stats[32] = st_[20]; g_enc_stats[33] = st_[21]; g_enc_stats[34] = st_[22]; }
