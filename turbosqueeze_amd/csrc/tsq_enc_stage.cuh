@@ -45,7 +45,8 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4_t lds_u32x4_t;
 
 struct StageCfg {
-    static constexpr uint32_t THREADS = 704;                      // eleven wavefronts
+    static constexpr uint32_t THREADS = 1024;                     // sixteen wavefronts are launched, eleven work (see the kernel)
+    static constexpr uint32_t THREADS_LEAN = 704;                 // the lean layout launches those eleven only
     static constexpr uint32_t EQ = 64, EV_WORDS = 4;              // events between WALK and ACCOUNT
     static constexpr uint32_t Q = 16;                             // items between ACCOUNT and BUILDER
     static constexpr uint32_t ITEM_WORDS = 80;
@@ -206,6 +207,7 @@ __device__ __forceinline__ void stage_hash(const uint8_t* src, uint64_t avail, u
         if (t + 3u > StageCfg::R && !stage_wait_seen(ctl, 5, t + 3u - StageCfg::R, parsed_seen, 0)) break;
         if (t + 1u > StageCfg::R && !stage_wait_seen(ctl, kCtlAccounted, t + 1u - StageCfg::R, accounted_seen, 0)) break;
         if (t + 1u > StageCfg::R && !stage_wait_seen(ctl, kCtlCommitted, t + 1u - StageCfg::R, committed_seen, 0)) break;
+        TSQ_TRACE(0, t);
         const uint32_t p = (t << 6) + lane;
         const uint4 w16 = w_next;
         w_next = ld128z(src, (uint64_t)p + 64u, avail);    // the next tile's words: this wave's only global access, a full iteration ahead
@@ -231,6 +233,7 @@ __device__ __forceinline__ void stage_hash(const uint8_t* src, uint64_t avail, u
         volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
         arr[kAH * 64] = h;
         arr[kAOwn * 64] = before | (id << 8) | (after != tag ? 0x1000u : 0u);     // owner before | this tile's id | another lane of the tile took the bucket
+        TSQ_TRACE(1, t);
         stage_publish(ctl, kCtlHashed, t + 1u, lane);
         hf_m3 = hf_m2; hf_m2 = hf_m1; hf_m1 = hf;
         id = id == 3u ? 1u : id + 1u;
@@ -318,6 +321,7 @@ __device__ __forceinline__ void stage_twins(uint32_t n, lds_u8_t* lds, uint32_t 
         arr[kATp1 * 64] = (uint32_t)twin_p1;  arr[(kATp1 + 1) * 64] = (uint32_t)(twin_p1 >> 32);
         arr[kATp2 * 64] = (uint32_t)twin_p2;  arr[(kATp2 + 1) * 64] = (uint32_t)(twin_p2 >> 32);
         arr[kATp3 * 64] = (uint32_t)twin_p3;  arr[(kATp3 + 1) * 64] = (uint32_t)(twin_p3 >> 32);
+        TSQ_TRACE(2, t);
         stage_publish(ctl, 2, t + 1u, lane);
         h_m3 = h_m2; h_m2 = h_m1; h_m1 = h;
     }
@@ -345,6 +349,7 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
     for (uint32_t t = parity; t < n_tiles; t += 2u) {
         MREG_BEGIN(10);
         if (!stage_wait_seen(ctl, 2, t + 1u, scanned_seen, 2)) break;
+        TSQ_TRACE(3, t);
         volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
         volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
         const uint32_t h = arr[kAH * 64];
@@ -359,6 +364,7 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         // ---- the table holds the visits of tiles <= t-4 (the COMMIT wave has published them: its stores are complete and the
         //      wavefronts of a workgroup share the vector L1): gather from it right away, without waiting for the parser ...
         if (t >= 4u && !stage_wait_seen(ctl, kCtlCommitted, t - 3u, committed_seen, 3)) break;
+        TSQ_TRACE(10, t);
         const uint32_t tv_old = table[h];                // (a plain load: an atomic one is waited for on the spot, and the gather's latency must stay hidden)
         MREG_END(12);
         MREG_BEGIN(11);
@@ -368,6 +374,7 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         uint32_t tv = tv_old;
         if (t >= 3u) {
             if (!stage_wait_tight(ctl, 5, t - 2u, 3)) break;
+            TSQ_TRACE(4, t);
             const uint32_t slot = 16u + 2u * ((t - 3u) & 7u);
             const uint32_t vis_lo = uniform(__hip_atomic_load(&ctl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             const uint32_t vis_hi = uniform(__hip_atomic_load(&ctl[slot + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -449,6 +456,7 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
 #ifdef TSQ_STATS
         if (t >= 3u) { st_[24] += (uint32_t)((uint32_t)__builtin_amdgcn_s_memtime() - uniform(ctl[40u + ((t - 3u) & 7u)])); st_[25] += 1; }
 #endif
+        TSQ_TRACE(5, t);
         stage_publish(ctl, parity ? kCtlMatchedOdd : 3u, t + 1u, lane);
         MREG_END(14);
         wbase = wbase + 128u >= StageCfg::WIN ? wbase + 128u - StageCfg::WIN : wbase + 128u;
@@ -493,6 +501,7 @@ __device__ __forceinline__ void stage_commit(uint32_t n, uint16_t* table, lds_u8
             late &= ~((uint64_t)rdlane(tin_lo, top) | ((uint64_t)rdlane(tin_hi, top) << 32) | (1ull << top));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the table stores are complete
+        TSQ_TRACE(6, t);
         stage_publish(ctl, kCtlCommitted, t + 1u, lane);
     }
 #ifdef TSQ_STATS
@@ -557,6 +566,7 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
             }
         }
         if (!stage_wait_tight(ctl, parity ? kCtlMatchedOdd : 3u, t + 1u, 6)) break;
+        TSQ_TRACE(11, t);
         uint32_t sw = arr[kASpan * 64];
         if (fix) { sw = fix_sw; arr[kASpan * 64] = fix_sw; arr[kALane * 64] = fix_lw; }
         if (clear_tp2) { sw |= 0x1000u; arr[kASpan * 64] = sw; }      // (SCAN's masks stay as they are: later tiles inherit from them)
@@ -583,6 +593,7 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
 #ifdef TSQ_STATS
         if (t >= 3u) { st_[24] += (uint32_t)((uint32_t)__builtin_amdgcn_s_memtime() - uniform(ctl[40u + ((t - 3u) & 7u)])); st_[25] += 1; }
 #endif
+        TSQ_TRACE(7, t);
         stage_publish(ctl, parity ? kCtlOrbitOdd : 4u, t + 1u, lane);
     }
 #ifdef TSQ_STATS
@@ -695,6 +706,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
 #endif
             }
             TSQ_CNT(15, 1);
+            TSQ_TRACE(8, t);
             volatile lds_u32_t* arr = recs + (t % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::ARR + lane;
             const uint32_t spanword = arr[kASpan * 64];
             const uint32_t lane_word = arr[kALane * 64];
@@ -855,6 +867,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
 #ifdef TSQ_STATS
         if (lane == 0) ctl[40u + (t & 7u)] = (uint32_t)__builtin_amdgcn_s_memtime();       // (the lag loop is timed from here)
 #endif
+        TSQ_TRACE(9, t);
         stage_publish(ctl, 5, t + 1u, lane);
         vall_p2 = vall_p1; vall_p1 = vall;
         REG_END(7);
@@ -1143,7 +1156,19 @@ __global__ __launch_bounds__(StageCfg::THREADS) void enc_stage_kernel(const uint
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t stage_lds[];
     const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u;
-    const uint32_t role = uniform(threadIdx.x >> 6);
+    // Wave w of a workgroup runs on SIMD w % 4 (read back from HW_ID in the instrumented build).  WALK, the serial stage, gets a SIMD
+    // to itself: the three other wavefronts of SIMD 0 leave right after the prologue.
+    //   SIMD 0: WALK            SIMD 1: ORBIT even, MATCH even, HASH, COMMIT     SIMD 2: ORBIT odd, MATCH odd, TWINS     SIMD 3: ACCOUNT, BUILDER, EMIT
+    enum : uint32_t { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNone, kRoleMatch0, kRoleMatch1, kRoleBuilder, kRoleHash, kRoleTwins, kRoleEmit, kRoleCommit };
+    // (the lean layout -- two workgroups per CU -- launches the eleven working wavefronts only: 2 x 16 do not fit a CU's wave slots)
+    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNone, kRoleMatch0, kRoleMatch1, kRoleBuilder,
+                                        kRoleNone, kRoleHash, kRoleTwins, kRoleEmit, kRoleNone, kRoleCommit, kRoleNone, kRoleNone };
+    constexpr uint32_t role_map_lean[16] = { kRoleWalk, kRoleOrbit0, kRoleMatch0, kRoleHash, kRoleEmit, kRoleBuilder, kRoleAccount, kRoleOrbit1,
+                                             kRoleCommit, kRoleTwins, kRoleMatch1, kRoleNone, kRoleNone, kRoleNone, kRoleNone, kRoleNone };
+    uint32_t role = kRoleNone;
+#pragma unroll
+    for (uint32_t w = 0; w < 16u; ++w) role = (threadIdx.x >> 6) == w ? (WINDOW ? role_map[w] : role_map_lean[w]) : role;
+    role = uniform(role);
     // block b of the launch lies at in + b * stride (stride = 4 MiB: one contiguous buffer; larger: a shard's blocks, each
     // followed by its own look-ahead bytes); its length follows from the virtual total n_total = (blocks - 1) * 4 MiB + last
     const uint64_t start = (uint64_t)b * stride;
@@ -1156,25 +1181,26 @@ __global__ __launch_bounds__(StageCfg::THREADS) void enc_stage_kernel(const uint
 
     {   // tsqInit (tsq_context.cpp:77-80), all five waves
         uint4* t4 = reinterpret_cast<uint4*>(table);
-        for (uint32_t k = threadIdx.x; k < kHashEntries * 2 / 16; k += StageCfg::THREADS) t4[k] = make_uint4(0, 0, 0, 0);
+        for (uint32_t k = threadIdx.x; k < kHashEntries * 2 / 16; k += blockDim.x) t4[k] = make_uint4(0, 0, 0, 0);
         if (threadIdx.x < 64) reinterpret_cast<uint32_t*>(stage_lds + StageCfg::off_ctl)[threadIdx.x] = 0;
         uint4* o4 = reinterpret_cast<uint4*>(stage_lds + StageCfg::off_owner);          // owner image: no valid entries
-        for (uint32_t k = threadIdx.x; k < (StageCfg::OWN_MASK + 1u) / 16; k += StageCfg::THREADS) o4[k] = make_uint4(0, 0, 0, 0);
+        for (uint32_t k = threadIdx.x; k < (StageCfg::OWN_MASK + 1u) / 16; k += blockDim.x) o4[k] = make_uint4(0, 0, 0, 0);
         if (threadIdx.x == 0) { out[0] = (uint8_t)n; out[1] = (uint8_t)(n >> 8); out[2] = (uint8_t)(n >> 16); }
     }
     __syncthreads();
     lds_u8_t* lds3 = (lds_u8_t*)stage_lds;
-    // Seven waves on four SIMDs (wave w runs on SIMD w % 4): WALK shares its SIMD with the emitter, which works once per 64
-    // symbols; ORBIT (which waits a third of its time) shares with the builder, MATCH with ACCOUNT.
-    if (role == 0) stage_walk<EXT, WINDOW>(src, avail, n, lds3, lane);
-    else if (role == 6) stage_account(n, lds3, lane);
-    else if (role == 8) stage_commit(n, table, lds3, lane);
-    else if (role == 3) stage_hash<WINDOW>(src, avail, n, lds3, lane);
-    else if (role == 9) stage_twins(n, lds3, lane);
-    else if (role == 2 || role == 10) stage_match<EXT, WINDOW>(src, avail, n, table, lds3, lane, role == 10 ? 1u : 0u);
-    else if (role == 1 || role == 7) stage_orbit<EXT>(n, lds3, lane, role == 7 ? 1u : 0u);
-    else if (role == 4) stream_emitter<StageCfg>(src, avail, out, lds3, lane, b, sizes, status);
-    else stream_builder<StageCfg>(lds3, lane);
+#ifdef TSQ_STATS
+    if (blockIdx.x == 0 && lane == 0) { uint32_t id; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id)); g_enc_trace[15 * 256 + (threadIdx.x >> 6)] = id; }
+#endif
+    if (role == kRoleWalk) stage_walk<EXT, WINDOW>(src, avail, n, lds3, lane);
+    else if (role == kRoleAccount) stage_account(n, lds3, lane);
+    else if (role == kRoleCommit) stage_commit(n, table, lds3, lane);
+    else if (role == kRoleHash) stage_hash<WINDOW>(src, avail, n, lds3, lane);
+    else if (role == kRoleTwins) stage_twins(n, lds3, lane);
+    else if (role == kRoleMatch0 || role == kRoleMatch1) stage_match<EXT, WINDOW>(src, avail, n, table, lds3, lane, role == kRoleMatch1 ? 1u : 0u);
+    else if (role == kRoleOrbit0 || role == kRoleOrbit1) stage_orbit<EXT>(n, lds3, lane, role == kRoleOrbit1 ? 1u : 0u);
+    else if (role == kRoleEmit) stream_emitter<StageCfg>(src, avail, out, lds3, lane, b, sizes, status);
+    else if (role == kRoleBuilder) stream_builder<StageCfg>(lds3, lane);
 }
 
 }  // namespace tsq

@@ -82,8 +82,8 @@ inline int launch_encode_kernels(tsqa_ctx* c, const uint8_t* in, size_t n, size_
     // window in LDS, candidate bytes from L2) lets two blocks share a CU; each is a little slower, together they are faster.
     const bool lean = v == 6 || (v == 0 && nb > (uint32_t)c->n_cus);
     if (lean) {
-        if (ext) TSQ_LAUNCH_ENC((enc_stage_kernel<true, false>), StageCfg::THREADS, StageCfg::total_lean);
-        else     TSQ_LAUNCH_ENC((enc_stage_kernel<false, false>), StageCfg::THREADS, StageCfg::total_lean);
+        if (ext) TSQ_LAUNCH_ENC((enc_stage_kernel<true, false>), StageCfg::THREADS_LEAN, StageCfg::total_lean);
+        else     TSQ_LAUNCH_ENC((enc_stage_kernel<false, false>), StageCfg::THREADS_LEAN, StageCfg::total_lean);
     } else {
         if (ext) TSQ_LAUNCH_ENC((enc_stage_kernel<true, true>), StageCfg::THREADS, StageCfg::total);
         else     TSQ_LAUNCH_ENC((enc_stage_kernel<false, true>), StageCfg::THREADS, StageCfg::total);

@@ -616,6 +616,10 @@ extern "C" int tsqa_debug_stats(unsigned long long* enc64, unsigned long long* d
     if (dec16 && hipMemcpyFromSymbol(dec16, HIP_SYMBOL(tsq::g_dec_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return TSQA_ERR_HIP;
     return TSQA_OK;
 }
+extern "C" int tsqa_debug_trace(uint32_t* out4096)
+{
+    return hipMemcpyFromSymbol(out4096, HIP_SYMBOL(tsq::g_enc_trace), 4096 * sizeof(uint32_t)) == hipSuccess ? TSQA_OK : TSQA_ERR_HIP;
+}
 extern "C" int tsqa_debug_syms(uint32_t* out8192)
 {
     return hipMemcpyFromSymbol(out8192, HIP_SYMBOL(tsq::g_dbg_syms), 8192 * sizeof(uint32_t)) == hipSuccess ? TSQA_OK : TSQA_ERR_HIP;
