@@ -23,17 +23,17 @@ tr = np.zeros(4096, dtype=np.uint32)
 assert L.tsqa_debug_trace(tr.ctypes.data) == 0
 tr = tr.reshape(16, 256).astype(np.int64)
 print("HW_ID of waves 0..15 (simd = bits 4..5):", " ".join("%d:simd%d" % (w, (int(tr[15, w]) >> 4) & 3) for w in range(16)))
-names = ["HASH go", "HASH pub", "TWINS pub", "MATCH go", "MATCH ver", "MATCH pub", "COMMIT pub", "ORBIT pub", "WALK go", "WALK pub", "gather", "ORBIT go", "MATCH pre"]
+names = ["HASH go", "HASH pub", "TWINS pub", "MATCH go", "MATCH ver", "MATCH pub", "COMMIT pub", "ORBIT pub", "WALK go", "WALK pub", "gather", "ORBIT go", "MATCH pre", "MATCH lds"]
 ix = {n: k for k, n in enumerate(names)}
 W = tr[ix["WALK pub"]]
 def rel(stage, t, ref_t):   # cycles from WALK's hand-over of tile ref_t to `stage` of tile t (mod 2^32)
     return int((tr[ix[stage], t] - W[ref_t] + (1 << 31)) % (1 << 32) - (1 << 31))
 print("cycles relative to WALK pub of tile t-3 (F3); period = F(t)-F(t-1)")
-hdr = ["tile", "period", "HASH go", "HASH pub", "TWINS pub", "MATCH go", "gather", "MATCH pre", "MATCH ver", "MATCH pub", "ORBIT go", "ORBIT pub", "WALK go", "WALK pub", "COMMIT(t-4)", "COMMIT(t-5)"]
+hdr = ["tile", "period", "HASH go", "HASH pub", "TWINS pub", "MATCH go", "MATCH lds", "gather", "MATCH pre", "MATCH ver", "MATCH pub", "ORBIT go", "ORBIT pub", "WALK go", "WALK pub", "COMMIT(t-4)", "COMMIT(t-5)"]
 print(" ".join("%11s" % h for h in hdr))
 acc = np.zeros(len(hdr) - 1); cnt = 0
 for t in range(8, 256):
-    vals = [rel("WALK pub", t, t - 1)] + [rel(sname, t, t - 3) for sname in ("HASH go", "HASH pub", "TWINS pub", "MATCH go", "gather", "MATCH pre", "MATCH ver", "MATCH pub", "ORBIT go", "ORBIT pub", "WALK go", "WALK pub")] + [rel("COMMIT pub", t - 4, t - 3), rel("COMMIT pub", t - 5, t - 3)]
+    vals = [rel("WALK pub", t, t - 1)] + [rel(sname, t, t - 3) for sname in ("HASH go", "HASH pub", "TWINS pub", "MATCH go", "MATCH lds", "gather", "MATCH pre", "MATCH ver", "MATCH pub", "ORBIT go", "ORBIT pub", "WALK go", "WALK pub")] + [rel("COMMIT pub", t - 4, t - 3), rel("COMMIT pub", t - 5, t - 3)]
     acc += np.array(vals); cnt += 1
     if t < 8 + rows:
         print("%11d " % t + " ".join("%11d" % v for v in vals))

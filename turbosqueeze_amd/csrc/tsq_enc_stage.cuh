@@ -44,14 +44,17 @@ namespace tsq {
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4_t lds_u32x4_t;
 
-struct StageCfg {
+// WINDOW = the standard layout (one block per CU: the input window ring in LDS, ten tile records); the lean layout (two blocks per CU)
+// has no window and eight records.
+template <bool WINDOW>
+struct StageCfgT {
     static constexpr uint32_t THREADS = 1024;                     // sixteen wavefronts are launched, eleven work (see the kernel)
     static constexpr uint32_t THREADS_LEAN = 704;                 // the lean layout launches those eleven only
     static constexpr uint32_t EQ = 64, EV_WORDS = 4;              // events between WALK and ACCOUNT
     static constexpr uint32_t Q = 16;                             // items between ACCOUNT and BUILDER
     static constexpr uint32_t ITEM_WORDS = 80;
     static constexpr uint32_t RING = 256;                          // symbol records between BUILDER and EMIT (four batches)
-    static constexpr uint32_t R = 8;                              // tile records in flight
+    static constexpr uint32_t R = WINDOW ? 10 : 8;                // tile records in flight (every stage waits less with ten; the lean layout has room for eight)
     static constexpr uint32_t OWN_MASK = 0x7FFFu;                 // owner image: hash folded to 15 bits
     static constexpr uint32_t WIN = 73728;                        // input window ring: the last 64 KiB of input and then some (a multiple of 64)
     static constexpr uint32_t W16 = 16;                           // word offset of the uint4-per-lane input words
@@ -64,13 +67,12 @@ struct StageCfg {
     static constexpr uint32_t off_ctl = off_rec + R * REC_WORDS * 4;           // u32[64]
     static constexpr uint32_t off_evq = off_ctl + 256;                         // u32[EQ * EV_WORDS]
     static constexpr uint32_t off_win = off_evq + EQ * EV_WORDS * 4;           // u8[WIN + 32]: the ring, its first 32 bytes mirrored at the end
-    static constexpr uint32_t total = off_win + WIN + 32;
-    static constexpr uint32_t total_lean = off_win;                            // without the window: two blocks fit one CU
+    static constexpr uint32_t total = WINDOW ? off_win + WIN + 32 : off_win;   // (without the window two blocks fit one CU)
+    static_assert(total <= (WINDOW ? 160u : 80u) * 1024u, "LDS budget");
 };
 // ctl words: 0 queue head, 1 queue tail, 2 tiles with twin masks, 3 / 35 even / odd tiles matched, 4 / 15 even / odd tiles with orbits,
 //            5 tiles walked, 6 stop, 7..9 BUILDER/EMIT (tsq_enc_builder.cuh), 10..14 WALK/ACCOUNT events, 33 tiles committed, 34 tiles hashed,
-//            16 + 2*(t&7): visited mask of tile t (lo, hi)
-// record: header words 0,1 = lanes that have an earlier twin inside the tile
+// record: header words 0,1 = lanes that have an earlier twin inside the tile (TWINS), 2,3 = the lanes the parse visited (WALK)
 //         per-lane arrays: 0 hash  1,2 twins in this tile (earlier lanes)  3,4 twins in tile t-1  5,6 twins in tile t-2
 //                          7 spanword  8 candidate | nibble << 24  9 orbit halt  10,11 orbit mask  12,13 twins in tile t-3
 //                          14 owner word (HASH -> TWINS)
@@ -188,6 +190,7 @@ __device__ __forceinline__ void stage_publish(lds_u32_t* ctl, uint32_t word, uin
 template <bool WINDOW>
 __device__ __forceinline__ void stage_hash(const uint8_t* src, uint64_t avail, uint32_t n, lds_u8_t* lds, uint32_t lane)
 {
+    using StageCfg = StageCfgT<WINDOW>;
     volatile lds_u8_t* owner = lds + StageCfg::off_owner;
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
@@ -244,8 +247,10 @@ __device__ __forceinline__ void stage_hash(const uint8_t* src, uint64_t avail, u
 #endif
 }
 
+template <bool WINDOW>
 __device__ __forceinline__ void stage_twins(uint32_t n, lds_u8_t* lds, uint32_t lane)
 {
+    using StageCfg = StageCfgT<WINDOW>;
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
     const uint32_t n_tiles = (n >> 6) + 3u;
@@ -334,6 +339,7 @@ __device__ __forceinline__ void stage_twins(uint32_t n, lds_u8_t* lds, uint32_t 
 template <bool EXT, bool WINDOW>
 __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, uint32_t n, uint16_t* table, lds_u8_t* lds, uint32_t lane, uint32_t parity)
 {
+    using StageCfg = StageCfgT<WINDOW>;
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
     constexpr uint32_t kDMin = EXT ? 128u : 64u;
@@ -375,9 +381,9 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         if (t >= 3u) {
             if (!stage_wait_tight(ctl, 5, t - 2u, 3)) break;
             TSQ_TRACE(4, t);
-            const uint32_t slot = 16u + 2u * ((t - 3u) & 7u);
-            const uint32_t vis_lo = uniform(__hip_atomic_load(&ctl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            const uint32_t vis_hi = uniform(__hip_atomic_load(&ctl[slot + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            lds_u32_t* vis = (lds_u32_t*)(recs + ((t - 3u) % StageCfg::R) * StageCfg::REC_WORDS + 2u);
+            const uint32_t vis_lo = uniform(__hip_atomic_load(&vis[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            const uint32_t vis_hi = uniform(__hip_atomic_load(&vis[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             const uint32_t hit_lo = tp3_lo & vis_lo, hit_hi = tp3_hi & vis_hi;
             const uint32_t q = hit_hi ? 63u - (uint32_t)__builtin_clz(hit_hi) : 31u - (uint32_t)__builtin_clz(hit_lo | 1u);
             if ((hit_lo | hit_hi) != 0u) tv = (((t - 3u) << 6) + q) & 0xFFFFu;
@@ -470,8 +476,10 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
 // The position table's writer.  Tile by tile, as soon as WALK has published a tile's visited lanes: their positions go to the
 // table (tsq_encode.cpp:79; among equal hashes the highest visited lane last) and into MATCH's filter for that tile (two filters,
 // used in turn).  `posted` tells MATCH the filter is ready; `committed` -- after the stores have completed -- that the table is.
+template <bool WINDOW>
 __device__ __forceinline__ void stage_commit(uint32_t n, uint16_t* table, lds_u8_t* lds, uint32_t lane)
 {
+    using StageCfg = StageCfgT<WINDOW>;
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
     const uint32_t n_tiles = (n >> 6) + 3u;
@@ -486,9 +494,9 @@ __device__ __forceinline__ void stage_commit(uint32_t n, uint16_t* table, lds_u8
         const uint32_t h = arr[kAH * 64];
         const uint32_t tin_lo = arr[kATin * 64], tin_hi = arr[(kATin + 1) * 64];
         const uint64_t tw = (uint64_t)uniform(rec[0]) | ((uint64_t)uniform(rec[1]) << 32);   // lanes with an earlier twin inside the tile
-        const uint32_t slot = 16u + 2u * (t & 7u);
-        const uint64_t vis = (uint64_t)uniform(__hip_atomic_load(&ctl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) |
-                             ((uint64_t)uniform(__hip_atomic_load(&ctl[slot + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) << 32);
+        lds_u32_t* visw = (lds_u32_t*)(rec + 2u);
+        const uint64_t vis = (uint64_t)uniform(__hip_atomic_load(&visw[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) |
+                             ((uint64_t)uniform(__hip_atomic_load(&visw[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) << 32);
         const uint32_t p = (t << 6) + lane;
         // among equal hashes the highest visited lane must win: lanes with an earlier twin store afterwards ...
         if (((vis & ~tw) >> lane) & 1ull) table[h] = (uint16_t)p;
@@ -510,9 +518,10 @@ __device__ __forceinline__ void stage_commit(uint32_t n, uint16_t* table, lds_u8
 }
 
 // --------------------------------------------------------------------------------------------- ORBIT
-template <bool EXT>
+template <bool EXT, bool WINDOW>
 __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t lane, uint32_t parity)
 {
+    using StageCfg = StageCfgT<WINDOW>;
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
     constexpr uint32_t kDMin = EXT ? 128u : 64u;
@@ -542,9 +551,9 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
             const bool only2 = (tp2_lo | tp2_hi) != 0u && nearer == 0u && p < tail_from;
             if (__ballot(only2) != 0ull) {
                 if (!stage_wait_seen(ctl, 5, t - 1u, parsed_seen, 5)) break;                   // the parser has finished tile t-2
-                const uint32_t slot = 16u + 2u * ((t - 2u) & 7u);
-                const uint32_t v2_lo = uniform(__hip_atomic_load(&ctl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                const uint32_t v2_hi = uniform(__hip_atomic_load(&ctl[slot + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                lds_u32_t* vis = (lds_u32_t*)(recs + ((t - 2u) % StageCfg::R) * StageCfg::REC_WORDS + 2u);
+                const uint32_t v2_lo = uniform(__hip_atomic_load(&vis[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                const uint32_t v2_hi = uniform(__hip_atomic_load(&vis[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 const uint32_t hit_lo = tp2_lo & v2_lo, hit_hi = tp2_hi & v2_hi;
                 clear_tp2 = only2;                       // visited or not, tile t-2 is settled for this lane
                 if (only2 && (hit_lo | hit_hi) != 0u) {
@@ -643,6 +652,7 @@ __device__ __forceinline__ uint32_t s_lsb64(uint64_t x)                   // x !
 template <bool EXT, bool WINDOW>
 __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, uint32_t n, lds_u8_t* lds, uint32_t lane)
 {
+    using StageCfg = StageCfgT<WINDOW>;
     volatile lds_u32_t* evq = (volatile lds_u32_t*)(lds + StageCfg::off_evq);
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
@@ -861,8 +871,8 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
         // ---- hand the tile's visited mask to MATCH (it commits the table) and move on
         REG_BEGIN(7);
         {
-            const uint32_t slot = 16u + 2u * (t & 7u);
-            if (lane < 2u) __hip_atomic_store(&ctl[slot + lane], lane ? (uint32_t)(vall >> 32) : (uint32_t)vall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            lds_u32_t* vis = (lds_u32_t*)(recs + (t % StageCfg::R) * StageCfg::REC_WORDS + 2u);
+            if (lane < 2u) __hip_atomic_store(&vis[lane], lane ? (uint32_t)(vall >> 32) : (uint32_t)vall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
 #ifdef TSQ_STATS
         if (lane == 0) ctl[40u + (t & 7u)] = (uint32_t)__builtin_amdgcn_s_memtime();       // (the lag loop is timed from here)
@@ -882,8 +892,10 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
 // All symbol state lives in uniform 32-bit integers (flags as 0/1, not bool: a bool that crosses a branch
 // becomes a 64-bit lane mask and costs VALU round trips), and the common paths are straight-line selects:
 // for a single wavefront a uniform branch costs more than the few instructions it skips.
+template <bool WINDOW>
 __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_t lane)
 {
+    using StageCfg = StageCfgT<WINDOW>;
     volatile lds_u32_t* queue = (volatile lds_u32_t*)(lds + StageCfg::off_queue);
     volatile lds_u32_t* evq = (volatile lds_u32_t*)(lds + StageCfg::off_evq);
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
@@ -1150,10 +1162,11 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
 }
 
 template <bool EXT, bool WINDOW>
-__global__ __launch_bounds__(StageCfg::THREADS) void enc_stage_kernel(const uint8_t* __restrict__ in, uint64_t n_total, uint64_t readable, uint64_t stride,
+__global__ __launch_bounds__(1024) void enc_stage_kernel(const uint8_t* __restrict__ in, uint64_t n_total, uint64_t readable, uint64_t stride,
                                                         uint8_t* __restrict__ slots, uint32_t* __restrict__ sizes,
                                                         uint16_t* __restrict__ tables, int32_t* __restrict__ status)
 {
+    using StageCfg = StageCfgT<WINDOW>;
     extern __shared__ __attribute__((aligned(16))) uint8_t stage_lds[];
     const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u;
     // Wave w of a workgroup runs on SIMD w % 4 (read back from HW_ID in the instrumented build).  WALK, the serial stage, gets a SIMD
@@ -1193,12 +1206,12 @@ __global__ __launch_bounds__(StageCfg::THREADS) void enc_stage_kernel(const uint
     if (blockIdx.x == 0 && lane == 0) { uint32_t id; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id)); g_enc_trace[15 * 256 + (threadIdx.x >> 6)] = id; }
 #endif
     if (role == kRoleWalk) stage_walk<EXT, WINDOW>(src, avail, n, lds3, lane);
-    else if (role == kRoleAccount) stage_account(n, lds3, lane);
-    else if (role == kRoleCommit) stage_commit(n, table, lds3, lane);
+    else if (role == kRoleAccount) stage_account<WINDOW>(n, lds3, lane);
+    else if (role == kRoleCommit) stage_commit<WINDOW>(n, table, lds3, lane);
     else if (role == kRoleHash) stage_hash<WINDOW>(src, avail, n, lds3, lane);
-    else if (role == kRoleTwins) stage_twins(n, lds3, lane);
+    else if (role == kRoleTwins) stage_twins<WINDOW>(n, lds3, lane);
     else if (role == kRoleMatch0 || role == kRoleMatch1) stage_match<EXT, WINDOW>(src, avail, n, table, lds3, lane, role == kRoleMatch1 ? 1u : 0u);
-    else if (role == kRoleOrbit0 || role == kRoleOrbit1) stage_orbit<EXT>(n, lds3, lane, role == kRoleOrbit1 ? 1u : 0u);
+    else if (role == kRoleOrbit0 || role == kRoleOrbit1) stage_orbit<EXT, WINDOW>(n, lds3, lane, role == kRoleOrbit1 ? 1u : 0u);
     else if (role == kRoleEmit) stream_emitter<StageCfg>(src, avail, out, lds3, lane, b, sizes, status);
     else if (role == kRoleBuilder) stream_builder<StageCfg>(lds3, lane);
 }

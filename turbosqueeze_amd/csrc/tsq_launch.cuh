@@ -49,7 +49,7 @@ inline int launch_encode_kernels(tsqa_ctx* c, const uint8_t* in, size_t n, size_
     {
         const void* const fns[4] = {reinterpret_cast<const void*>(enc_stage_kernel<true, true>), reinterpret_cast<const void*>(enc_stage_kernel<false, true>),
                                     reinterpret_cast<const void*>(enc_stage_kernel<true, false>), reinterpret_cast<const void*>(enc_stage_kernel<false, false>)};
-        const uint32_t bytes[4] = {StageCfg::total, StageCfg::total, StageCfg::total_lean, StageCfg::total_lean};
+        const uint32_t bytes[4] = {StageCfgT<true>::total, StageCfgT<true>::total, StageCfgT<false>::total, StageCfgT<false>::total};
         if (int rc = raise_lds_limit(c, attr_devices, fns, bytes)) return rc;
     }
     const int v = c->enc_variant;
@@ -82,11 +82,11 @@ inline int launch_encode_kernels(tsqa_ctx* c, const uint8_t* in, size_t n, size_
     // window in LDS, candidate bytes from L2) lets two blocks share a CU; each is a little slower, together they are faster.
     const bool lean = v == 6 || (v == 0 && nb > (uint32_t)c->n_cus);
     if (lean) {
-        if (ext) TSQ_LAUNCH_ENC((enc_stage_kernel<true, false>), StageCfg::THREADS_LEAN, StageCfg::total_lean);
-        else     TSQ_LAUNCH_ENC((enc_stage_kernel<false, false>), StageCfg::THREADS_LEAN, StageCfg::total_lean);
+        if (ext) TSQ_LAUNCH_ENC((enc_stage_kernel<true, false>), StageCfgT<false>::THREADS_LEAN, StageCfgT<false>::total);
+        else     TSQ_LAUNCH_ENC((enc_stage_kernel<false, false>), StageCfgT<false>::THREADS_LEAN, StageCfgT<false>::total);
     } else {
-        if (ext) TSQ_LAUNCH_ENC((enc_stage_kernel<true, true>), StageCfg::THREADS, StageCfg::total);
-        else     TSQ_LAUNCH_ENC((enc_stage_kernel<false, true>), StageCfg::THREADS, StageCfg::total);
+        if (ext) TSQ_LAUNCH_ENC((enc_stage_kernel<true, true>), StageCfgT<true>::THREADS, StageCfgT<true>::total);
+        else     TSQ_LAUNCH_ENC((enc_stage_kernel<false, true>), StageCfgT<true>::THREADS, StageCfgT<true>::total);
     }
     return 0;
 }
