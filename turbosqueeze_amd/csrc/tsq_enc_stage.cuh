@@ -379,11 +379,19 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         // keep theirs.
         uint32_t tv = tv_old;
         if (t >= 3u) {
-            if (!stage_wait_tight(ctl, 5, t - 2u, 3)) break;
+            volatile lds_u32_t* vis = recs + ((t - 3u) % StageCfg::R) * StageCfg::REC_WORDS + 2u;
+            uint32_t vis_lo, vis_hi;
+            {   // (counter and visited mask requested together: one LDS round trip less on the lag loop)
+                const uint32_t seen_v = ((volatile lds_u32_t*)ctl)[5];
+                uint32_t a = vis[0], b = vis[1];
+                asm volatile("" ::: "memory");
+                if (uniform(seen_v) < t - 2u) {
+                    if (!stage_wait_tight(ctl, 5, t - 2u, 3)) break;
+                    a = vis[0]; b = vis[1];
+                }
+                vis_lo = uniform(a); vis_hi = uniform(b);
+            }
             TSQ_TRACE(4, t);
-            lds_u32_t* vis = (lds_u32_t*)(recs + ((t - 3u) % StageCfg::R) * StageCfg::REC_WORDS + 2u);
-            const uint32_t vis_lo = uniform(__hip_atomic_load(&vis[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            const uint32_t vis_hi = uniform(__hip_atomic_load(&vis[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             const uint32_t hit_lo = tp3_lo & vis_lo, hit_hi = tp3_hi & vis_hi;
             const uint32_t q = hit_hi ? 63u - (uint32_t)__builtin_clz(hit_hi) : 31u - (uint32_t)__builtin_clz(hit_lo | 1u);
             if ((hit_lo | hit_hi) != 0u) tv = (((t - 3u) << 6) + q) & 0xFFFFu;
@@ -574,9 +582,18 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
                 }
             }
         }
-        if (!stage_wait_tight(ctl, parity ? kCtlMatchedOdd : 3u, t + 1u, 6)) break;
+        // (counter and record word requested together, as in WALK: one LDS round trip less on the lag loop)
+        uint32_t sw;
+        {
+            const uint32_t seen_v = ((volatile lds_u32_t*)ctl)[parity ? kCtlMatchedOdd : 3u];
+            sw = arr[kASpan * 64];
+            asm volatile("" ::: "memory");
+            if (uniform(seen_v) < t + 1u) {
+                if (!stage_wait_tight(ctl, parity ? kCtlMatchedOdd : 3u, t + 1u, 6)) break;
+                sw = arr[kASpan * 64];
+            }
+        }
         TSQ_TRACE(11, t);
-        uint32_t sw = arr[kASpan * 64];
         if (fix) { sw = fix_sw; arr[kASpan * 64] = fix_sw; arr[kALane * 64] = fix_lw; }
         if (clear_tp2) { sw |= 0x1000u; arr[kASpan * 64] = sw; }      // (SCAN's masks stay as they are: later tiles inherit from them)
         // the whole orbit of every lane, by pointer doubling: `nx` = where the orbit started at this lane halts
@@ -666,19 +683,20 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
     unsigned long long st_[32] = {0};
 #endif
 
-    auto ev_push = [&](uint32_t kind, uint32_t a, uint32_t b, uint32_t c) {
-        if (ev_head - ev_tail_seen >= StageCfg::EQ) {
+    auto ev_wait_space = [&]() {
 #ifdef TSQ_STATS
-            const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
+        const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
 #endif
-            while (ev_head - ev_tail_seen >= StageCfg::EQ) {
-                ev_tail_seen = uniform(__hip_atomic_load(&ctl[kCtlEvTail], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                if (ev_head - ev_tail_seen >= StageCfg::EQ) __builtin_amdgcn_s_sleep(1);
-            }
-#ifdef TSQ_STATS
-            st_[9] += __builtin_amdgcn_s_memtime() - w0_;
-#endif
+        while (ev_head - ev_tail_seen >= StageCfg::EQ) {
+            ev_tail_seen = uniform(__hip_atomic_load(&ctl[kCtlEvTail], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (ev_head - ev_tail_seen >= StageCfg::EQ) __builtin_amdgcn_s_sleep(1);
         }
+#ifdef TSQ_STATS
+        st_[9] += __builtin_amdgcn_s_memtime() - w0_;
+#endif
+    };
+    auto ev_push = [&](uint32_t kind, uint32_t a, uint32_t b, uint32_t c) {
+        if (ev_head - ev_tail_seen >= StageCfg::EQ) ev_wait_space();
         volatile lds_u32_t* e = evq + (ev_head % StageCfg::EQ) * StageCfg::EV_WORDS;
         uint32_t hv = kind;
         asm volatile("v_writelane_b32 %0, %1, 1" : "+v"(hv) : "s"(a));
@@ -691,41 +709,55 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
         __hip_atomic_store(&ctl[kCtlEvHead], ev_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     // the 16 input bytes at a position of tiles t-2 .. t, from the tile records (one LDS address for the whole wave)
-    auto words_at = [&](uint32_t pos) -> uint4 {
-        const u32x4_t q = *(volatile lds_u32x4_t*)(recs + ((pos >> 6) % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::W16 + (pos & 63u) * 4u);
+    auto words_at = [&](uint32_t slot, uint32_t pos) -> uint4 {
+        const u32x4_t q = *(volatile lds_u32x4_t*)(recs + slot * StageCfg::REC_WORDS + StageCfg::W16 + (pos & 63u) * 4u);
         return make_uint4(q.x, q.y, q.z, q.w);
     };
 
     uint32_t wbase = 0;                // (t * 64) % WIN
+    uint32_t rec_slot = 0;             // t % R
     TSQ_BEGIN();
-    for (uint32_t t = 0; done == 0u; ++t, wbase = wbase + 64u == StageCfg::WIN ? 0u : wbase + 64u) {
+    for (uint32_t t = 0; done == 0u; ++t, wbase = wbase + 64u == StageCfg::WIN ? 0u : wbase + 64u, rec_slot = rec_slot + 1u == StageCfg::R ? 0u : rec_slot + 1u) {
         const uint32_t base = t << 6;
-        uint64_t vall = 0;
+        uint64_t vall = 0, Vtail = 0;
         if (v < base + 64u) {
             REG_BEGIN(0); REG_END(0);
             REG_BEGIN(1);
             // (the serial stage polls without sleeping: a wake-up from s_sleep costs it up to 64 cycles per hand-off)
             const uint32_t orbit_word = (t & 1u) ? kCtlOrbitOdd : 4u;
-            if (!stage_ready(ctl, orbit_word, t + 1u)) {
+            volatile lds_u32_t* arr = recs + rec_slot * StageCfg::REC_WORDS + StageCfg::ARR + lane;
+            uint32_t spanword, lane_word, nx, orb_lo, orb_hi, tin_lo, tin_hi, tp1_lo, tp1_hi, tp2r_lo, tp2r_hi;
+            auto load_record = [&]() {
+                spanword = arr[kASpan * 64];
+                lane_word = arr[kALane * 64];
+                nx = arr[kANx * 64];
+                orb_lo = arr[kAOrb * 64]; orb_hi = arr[(kAOrb + 1) * 64];
+                tin_lo = arr[kATin * 64]; tin_hi = arr[(kATin + 1) * 64];
+                tp1_lo = arr[kATp1 * 64]; tp1_hi = arr[(kATp1 + 1) * 64];
+                tp2r_lo = arr[kATp2 * 64]; tp2r_hi = arr[(kATp2 + 1) * 64];
+            };
+            // The counter and the record's words are requested together: the LDS serves a wavefront's requests in order, so when the
+            // counter (asked for first) says the record is there, the words that came back behind it are the record's; only when it is
+            // not there yet (the lag loop is late) are they asked for again.  One LDS round trip per tile less on the serial stage.
+            {
+                const uint32_t seen_v = ((volatile lds_u32_t*)ctl)[orbit_word];
+                load_record();
+                asm volatile("" ::: "memory");
+                if (uniform(seen_v) < t + 1u) {
 #ifdef TSQ_STATS
-                const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
+                    const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
 #endif
-                while (!stage_ready(ctl, orbit_word, t + 1u)) {}
+                    while (!stage_ready(ctl, orbit_word, t + 1u)) {}
 #ifdef TSQ_STATS
-                st_[8] += __builtin_amdgcn_s_memtime() - w0_;
+                    st_[8] += __builtin_amdgcn_s_memtime() - w0_;
 #endif
+                    load_record();
+                }
             }
             TSQ_CNT(15, 1);
             TSQ_TRACE(8, t);
-            volatile lds_u32_t* arr = recs + (t % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::ARR + lane;
-            const uint32_t spanword = arr[kASpan * 64];
-            const uint32_t lane_word = arr[kALane * 64];
-            const uint32_t nx = arr[kANx * 64];
-            const uint32_t orb_lo = arr[kAOrb * 64], orb_hi = arr[(kAOrb + 1) * 64];
-            const uint32_t tin_lo = arr[kATin * 64], tin_hi = arr[(kATin + 1) * 64];
-            const uint32_t tp1_lo = arr[kATp1 * 64], tp1_hi = arr[(kATp1 + 1) * 64];
             const uint32_t settled = (spanword & 0x1000u) ? 0u : 0xFFFFFFFFu;     // ORBIT has settled the lane's twins in tile t-2
-            const uint32_t tp2_lo = arr[kATp2 * 64] & settled, tp2_hi = arr[(kATp2 + 1) * 64] & settled;
+            const uint32_t tp2_lo = tp2r_lo & settled, tp2_hi = tp2r_hi & settled;
             const uint64_t hard = __ballot((spanword & 0x100u) != 0u);
             const uint64_t near_m = __ballot((spanword & 0x800u) != 0u);
             const uint64_t certain_m = __ballot((spanword & 0x400u) != 0u);
@@ -755,9 +787,9 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                 if (__builtin_expect(s_nz64(V & near_m), 0)) {
                     // near-twin lanes (classed "no match" on the assumption that a twin at most 3 back is visited) are
                     // the other way round: they are right exactly when such a twin was visited
-                    uint32_t a_lo = in_lo, a_hi = in_hi;
-                    asm volatile("; near twins" : "+v"(a_lo), "+v"(a_hi));             // keeps this block's arithmetic out of the tile prologue
-                    const uint32_t pv_lo = tp1_lo & (uint32_t)vall_p1, pv_hi = tp1_hi & (uint32_t)(vall_p1 >> 32);
+                    uint32_t a_lo = in_lo, a_hi = in_hi, b_lo = tp1_lo, b_hi = tp1_hi;
+                    asm volatile("; near twins" : "+v"(a_lo), "+v"(a_hi), "+v"(b_lo), "+v"(b_hi));   // keeps this block's arithmetic out of the tile prologue
+                    const uint32_t pv_lo = b_lo & (uint32_t)vall_p1, pv_hi = b_hi & (uint32_t)(vall_p1 >> 32);
                     const bool has_in = (a_lo | a_hi) != 0u, has_prev = (pv_lo | pv_hi) != 0u;
                     const uint32_t nearest = a_hi ? 63u - (uint32_t)__builtin_clz(a_hi) : 31u - (uint32_t)__builtin_clz(a_lo | 1u);
                     const uint32_t nearest_prev = pv_hi ? 63u - (uint32_t)__builtin_clz(pv_hi) : 31u - (uint32_t)__builtin_clz(pv_lo | 1u);
@@ -799,7 +831,9 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                         const uint64_t pick = in_tile ? in_tile : in_p1 ? in_p1 : in_p2;
                         const uint32_t back = in_tile ? 0u : in_p1 ? 64u : 128u;
                         cand = base - back + msb64(pick);
-                        k = uniform(prefix16(words_at(i), words_at(cand)));
+                        const uint32_t tiles_back = back >> 6;
+                        const uint32_t cand_slot = rec_slot >= tiles_back ? rec_slot - tiles_back : rec_slot + StageCfg::R - tiles_back;
+                        k = uniform(prefix16(words_at(rec_slot, i), words_at(cand_slot, cand)));
                         twin_cand = 1;
                         TSQ_CNT(17, in_tile ? 1 : 0); TSQ_CNT(18, (!in_tile && in_p1) ? 1 : 0); TSQ_CNT(19, (!in_tile && !in_p1) ? 1 : 0);
                         if (EXT && k >= 16u) {
@@ -864,21 +898,24 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                 REG_END(5);
                 if (L >= 64u || done != 0u) break;
             }
-            REG_BEGIN(6);
-            if (Vacc != 0ull) ev_push(kEvSeg, base, (uint32_t)Vacc, (uint32_t)(Vacc >> 32));
-            REG_END(6);
+            Vtail = Vacc;
         }
-        // ---- hand the tile's visited mask to MATCH (it commits the table) and move on
+        // ---- the tile's last segment goes to ACCOUNT, its visited mask to MATCH and COMMIT (they patch / commit the table), and the
+        //      tile counter moves on: four stores of lane 0 in one stretch (the LDS executes them in this order)
+        // ---- the tile's visited mask goes to MATCH and COMMIT (they patch / commit the table) and the tile counter moves on: the lag
+        //      loop WALK(t) -> MATCH(t+3) -> ORBIT(t+3) -> WALK(t+3) waits for exactly this, so it goes out first; the tile's last
+        //      segment for ACCOUNT follows
         REG_BEGIN(7);
         {
-            lds_u32_t* vis = (lds_u32_t*)(recs + (t % StageCfg::R) * StageCfg::REC_WORDS + 2u);
+            lds_u32_t* vis = (lds_u32_t*)(recs + rec_slot * StageCfg::REC_WORDS + 2u);
             if (lane < 2u) __hip_atomic_store(&vis[lane], lane ? (uint32_t)(vall >> 32) : (uint32_t)vall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        stage_publish(ctl, 5, t + 1u, lane);
+        if (Vtail != 0ull) ev_push(kEvSeg, base, (uint32_t)Vtail, (uint32_t)(Vtail >> 32));
 #ifdef TSQ_STATS
         if (lane == 0) ctl[40u + (t & 7u)] = (uint32_t)__builtin_amdgcn_s_memtime();       // (the lag loop is timed from here)
 #endif
         TSQ_TRACE(9, t);
-        stage_publish(ctl, 5, t + 1u, lane);
         vall_p2 = vall_p1; vall_p1 = vall;
         REG_END(7);
     }
