@@ -1,4 +1,4 @@
-// tsq_enc_stage.cuh -- staged block encoder for gfx950: eleven wavefronts per block (kernel variant 0).
+// tsq_enc_stage.cuh -- staged block encoder for gfx950: twelve wavefronts per block (kernel variant 0).
 //
 // A single wavefront issues about one instruction every five cycles, and the greedy parse of a block is
 // serial (tsq_encode.cpp:72-187: the position table is a function of the parse).  So the block's work
@@ -10,6 +10,7 @@
 //   TWINS    the exact same-hash ("twin") masks of every lane against the earlier lanes of its tile and the
 //            three tiles before: inherited from the bucket owner's own masks when the owner has the lane's
 //            hash (no search), settled with ballots on a fold collision.
+//   NEAR     the common prefix of every lane with its nearest twin, ahead of time (WALK's hazard lanes mostly need exactly that).
 //   MATCH x2 (even / odd tiles) the candidates: gather from the position table, patch with the visited twins
 //            of tile t-3 (mask test), candidate bytes from the input window ring in LDS, common prefix,
 //            lane classes (certain match / certain literal / hazard).
@@ -48,8 +49,8 @@ typedef __attribute__((address_space(3))) u32x4_t lds_u32x4_t;
 // has no window and eight records.
 template <bool WINDOW>
 struct StageCfgT {
-    static constexpr uint32_t THREADS = 1024;                     // sixteen wavefronts are launched, eleven work (see the kernel)
-    static constexpr uint32_t THREADS_LEAN = 704;                 // the lean layout launches those eleven only
+    static constexpr uint32_t THREADS = 1024;                     // sixteen wavefronts are launched, twelve work (see the kernel)
+    static constexpr uint32_t THREADS_LEAN = 768;                 // the lean layout launches the twelve working ones only
     static constexpr uint32_t EQ = 64, EV_WORDS = 4;              // events between WALK and ACCOUNT
     static constexpr uint32_t Q = 16;                             // items between ACCOUNT and BUILDER
     static constexpr uint32_t ITEM_WORDS = 80;
@@ -75,13 +76,13 @@ struct StageCfgT {
 // record: header words 0,1 = lanes that have an earlier twin inside the tile (TWINS), 2,3 = the lanes the parse visited (WALK)
 //         per-lane arrays: 0 hash  1,2 twins in this tile (earlier lanes)  3,4 twins in tile t-1  5,6 twins in tile t-2
 //                          7 spanword  8 candidate | nibble << 24  9 orbit halt  10,11 orbit mask  12,13 twins in tile t-3
-//                          14 owner word (HASH -> TWINS)
+//                          14 owner word (HASH -> TWINS), then the nearest twin's word (NEAR -> WALK)
 // spanword: natural span (bits 0..7) | hard (8) | has a twin (9) | certain match (10) | near twin (11) | twins of t-2 settled (12) | common prefix (16..23)
 enum : uint32_t { kAH = 0, kATin = 1, kATp1 = 3, kATp2 = 5, kASpan = 7, kALane = 8, kANx = 9, kAOrb = 10, kATp3 = 12, kAOwn = 14 };
 // events between WALK and ACCOUNT, and their ctl words (10 events produced, 11 consumed, 12 queries answered, 13 the answer,
 // 14 the tile ACCOUNT works on: the tiles before it are accounted)
 enum : uint32_t { kEvSeg = 1, kEvHaz = 2, kEvEnd = 3 };
-enum : uint32_t { kCtlEvHead = 10, kCtlEvTail = 11, kCtlReplies = 12, kCtlReplyValue = 13, kCtlAccounted = 14, kCtlOrbitOdd = 15, kCtlCommitted = 33, kCtlHashed = 34, kCtlMatchedOdd = 35 };
+enum : uint32_t { kCtlEvHead = 10, kCtlEvTail = 11, kCtlReplies = 12, kCtlReplyValue = 13, kCtlAccounted = 14, kCtlOrbitOdd = 15, kCtlCommitted = 33, kCtlHashed = 34, kCtlMatchedOdd = 35, kCtlNear = 36 };
 
 // Instrumented builds time only the spin loops (and only when they actually spin): s_memtime costs a few
 // hundred cycles, so finer timing distorts the pipeline it measures.  busy = total - waited.
@@ -335,6 +336,52 @@ __device__ __forceinline__ void stage_twins(uint32_t n, lds_u8_t* lds, uint32_t 
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------- NEAR
+// Off the critical loop, two or three tiles ahead of WALK: for every lane that has a twin in the window (its own tile and the two
+// before), the common prefix with its NEAREST twin.  When WALK meets a hazard lane, the candidate is the most recent VISITED twin;
+// five times out of six that is the nearest twin, and then the prefix is here already (no LDS round trip and no byte compare on
+// the serial stage).  Word per lane (it takes the place of HASH's owner word, which TWINS has consumed by now):
+//   bit 15 valid | tiles back (0..2) << 12 | twin's lane << 6 | common prefix (0..16)
+template <bool EXT, bool WINDOW>
+__device__ __forceinline__ void stage_near(uint32_t n, lds_u8_t* lds, uint32_t lane)
+{
+    using StageCfg = StageCfgT<WINDOW>;
+    volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
+    lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
+    const uint32_t n_tiles = (n >> 6) + 3u;
+    uint32_t scanned_seen = 0, slot = 0;
+#ifdef TSQ_STATS
+    unsigned long long st_[32] = {0};
+#endif
+    TSQ_BEGIN();
+    for (uint32_t t = 0; t < n_tiles; ++t, slot = slot + 1u == StageCfg::R ? 0u : slot + 1u) {
+        if (!stage_wait_seen(ctl, 2, t + 1u, scanned_seen, 0)) break;
+        volatile lds_u32_t* rec = recs + slot * StageCfg::REC_WORDS;
+        volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
+        const uint32_t tin_lo = arr[kATin * 64], tin_hi = arr[(kATin + 1) * 64];
+        const uint32_t tp1_lo = arr[kATp1 * 64], tp1_hi = arr[(kATp1 + 1) * 64];
+        const uint32_t tp2_lo = arr[kATp2 * 64], tp2_hi = arr[(kATp2 + 1) * 64];
+        const bool in0 = (tin_lo | tin_hi) != 0u, in1 = (tp1_lo | tp1_hi) != 0u, in2 = (tp2_lo | tp2_hi) != 0u;
+        uint32_t word = 0;
+        if (__ballot(in0 || in1 || in2) != 0ull) {
+            const uint32_t m_lo = in0 ? tin_lo : in1 ? tp1_lo : tp2_lo, m_hi = in0 ? tin_hi : in1 ? tp1_hi : tp2_hi;
+            const uint32_t q = m_hi ? 63u - (uint32_t)__builtin_clz(m_hi) : 31u - (uint32_t)__builtin_clz(m_lo | 1u);
+            const uint32_t back = in0 ? 0u : in1 ? 1u : 2u;
+            const uint32_t qslot = slot >= back ? slot - back : slot + StageCfg::R - back;
+            const u32x4_t a = *(volatile lds_u32x4_t*)(rec + StageCfg::W16 + lane * 4u);
+            const u32x4_t b = *(volatile lds_u32x4_t*)(recs + qslot * StageCfg::REC_WORDS + StageCfg::W16 + q * 4u);
+            const uint32_t k = prefix16(make_uint4(a.x, a.y, a.z, a.w), make_uint4(b.x, b.y, b.z, b.w));
+            // (with extensions a prefix of 16 may go on: WALK takes the long way round for those)
+            if ((in0 || in1 || in2) && !(EXT && k >= 16u)) word = 0x8000u | (back << 12) | (q << 6) | k;
+        }
+        arr[kAOwn * 64] = word;
+        stage_publish(ctl, kCtlNear, t + 1u, lane);
+    }
+#ifdef TSQ_STATS
+    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[55] = st_[0]; g_enc_stats[56] = TSQ_TOTAL(); }
+#endif
+}
+
 // --------------------------------------------------------------------------------------------- MATCH
 template <bool EXT, bool WINDOW>
 __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, uint32_t n, uint16_t* table, lds_u8_t* lds, uint32_t lane, uint32_t parity)
@@ -540,7 +587,7 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
 #endif
     TSQ_BEGIN();
     // two ORBIT wavefronts take the even and the odd tiles (nothing is carried from tile to tile)
-    uint32_t scanned_seen = 0, parsed_seen = 0;
+    uint32_t scanned_seen = 0, parsed_seen = 0, near_seen = 0;
     for (uint32_t t = parity; t < n_tiles; t += 2u) {
         volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
         volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
@@ -613,6 +660,8 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
             const uint32_t ohi = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)(uint32_t)(orb >> 32));
             if ((nx & 0x80u) == 0u) { nx = nx2; orb |= (uint64_t)olo | ((uint64_t)ohi << 32); }
         }
+        // (WALK also reads NEAR's word of the tile: NEAR runs tiles ahead, this wait is satisfied by what was read long ago)
+        if (!stage_wait_seen(ctl, kCtlNear, t + 1u, near_seen, 6)) break;
         arr[kANx * 64] = nx;
         arr[kAOrb * 64] = (uint32_t)orb;
         arr[(kAOrb + 1) * 64] = (uint32_t)(orb >> 32);
@@ -726,7 +775,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
             // (the serial stage polls without sleeping: a wake-up from s_sleep costs it up to 64 cycles per hand-off)
             const uint32_t orbit_word = (t & 1u) ? kCtlOrbitOdd : 4u;
             volatile lds_u32_t* arr = recs + rec_slot * StageCfg::REC_WORDS + StageCfg::ARR + lane;
-            uint32_t spanword, lane_word, nx, orb_lo, orb_hi, tin_lo, tin_hi, tp1_lo, tp1_hi, tp2r_lo, tp2r_hi;
+            uint32_t spanword, lane_word, nx, orb_lo, orb_hi, tin_lo, tin_hi, tp1_lo, tp1_hi, tp2r_lo, tp2r_hi, nearw;
             auto load_record = [&]() {
                 spanword = arr[kASpan * 64];
                 lane_word = arr[kALane * 64];
@@ -735,6 +784,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                 tin_lo = arr[kATin * 64]; tin_hi = arr[(kATin + 1) * 64];
                 tp1_lo = arr[kATp1 * 64]; tp1_hi = arr[(kATp1 + 1) * 64];
                 tp2r_lo = arr[kATp2 * 64]; tp2r_hi = arr[(kATp2 + 1) * 64];
+                nearw = arr[kAOwn * 64];
             };
             // The counter and the record's words are requested together: the LDS serves a wavefront's requests in order, so when the
             // counter (asked for first) says the record is there, the words that came back behind it are the record's; only when it is
@@ -830,10 +880,16 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                     if (in_tile | in_p1 | in_p2) {
                         const uint64_t pick = in_tile ? in_tile : in_p1 ? in_p1 : in_p2;
                         const uint32_t back = in_tile ? 0u : in_p1 ? 64u : 128u;
-                        cand = base - back + msb64(pick);
-                        const uint32_t tiles_back = back >> 6;
-                        const uint32_t cand_slot = rec_slot >= tiles_back ? rec_slot - tiles_back : rec_slot + StageCfg::R - tiles_back;
-                        k = uniform(prefix16(words_at(rec_slot, i), words_at(cand_slot, cand)));
+                        const uint32_t pick_lane = msb64(pick);
+                        cand = base - back + pick_lane;
+                        // the nearest twin's prefix is there already (NEAR); another twin's is taken from the tile records
+                        const uint32_t nw = rdlane(nearw, L);
+                        if (nw == (0x8000u | (back << 6) | (pick_lane << 6) | (nw & 63u))) { k = nw & 63u; TSQ_CNT(16, 1); }
+                        else {
+                            const uint32_t tiles_back = back >> 6;
+                            const uint32_t cand_slot = rec_slot >= tiles_back ? rec_slot - tiles_back : rec_slot + StageCfg::R - tiles_back;
+                            k = uniform(prefix16(words_at(rec_slot, i), words_at(cand_slot, cand)));
+                        }
                         twin_cand = 1;
                         TSQ_CNT(17, in_tile ? 1 : 0); TSQ_CNT(18, (!in_tile && in_p1) ? 1 : 0); TSQ_CNT(19, (!in_tile && !in_p1) ? 1 : 0);
                         if (EXT && k >= 16u) {
@@ -1207,14 +1263,15 @@ __global__ __launch_bounds__(1024) void enc_stage_kernel(const uint8_t* __restri
     extern __shared__ __attribute__((aligned(16))) uint8_t stage_lds[];
     const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u;
     // Wave w of a workgroup runs on SIMD w % 4 (read back from HW_ID in the instrumented build).  WALK, the serial stage, gets a SIMD
-    // to itself: the three other wavefronts of SIMD 0 leave right after the prologue.
-    //   SIMD 0: WALK            SIMD 1: ORBIT even, MATCH even, HASH, COMMIT     SIMD 2: ORBIT odd, MATCH odd, TWINS     SIMD 3: ACCOUNT, BUILDER, EMIT
-    enum : uint32_t { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNone, kRoleMatch0, kRoleMatch1, kRoleBuilder, kRoleHash, kRoleTwins, kRoleEmit, kRoleCommit };
-    // (the lean layout -- two workgroups per CU -- launches the eleven working wavefronts only: 2 x 16 do not fit a CU's wave slots)
-    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNone, kRoleMatch0, kRoleMatch1, kRoleBuilder,
+    // almost to itself (NEAR, a light stage, shares it): the two other wavefronts of SIMD 0 leave right after the prologue.
+    //   SIMD 0: WALK, NEAR      SIMD 1: ORBIT even, MATCH even, HASH, COMMIT     SIMD 2: ORBIT odd, MATCH odd, TWINS     SIMD 3: ACCOUNT, BUILDER, EMIT
+    // (measured and dropped: s_setprio on the lag loop's stages or on WALK, COMMIT / EMIT / HASH on SIMD 0, NEAR on SIMD 2 or 3: all within 0.3 %)
+    enum : uint32_t { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNone, kRoleMatch0, kRoleMatch1, kRoleBuilder, kRoleHash, kRoleTwins, kRoleEmit, kRoleCommit, kRoleNear };
+    // (the lean layout -- two workgroups per CU -- launches the twelve working wavefronts only: 2 x 16 do not fit a CU's wave slots)
+    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleBuilder,
                                         kRoleNone, kRoleHash, kRoleTwins, kRoleEmit, kRoleNone, kRoleCommit, kRoleNone, kRoleNone };
     constexpr uint32_t role_map_lean[16] = { kRoleWalk, kRoleOrbit0, kRoleMatch0, kRoleHash, kRoleEmit, kRoleBuilder, kRoleAccount, kRoleOrbit1,
-                                             kRoleCommit, kRoleTwins, kRoleMatch1, kRoleNone, kRoleNone, kRoleNone, kRoleNone, kRoleNone };
+                                             kRoleCommit, kRoleTwins, kRoleMatch1, kRoleNear, kRoleNone, kRoleNone, kRoleNone, kRoleNone };
     uint32_t role = kRoleNone;
 #pragma unroll
     for (uint32_t w = 0; w < 16u; ++w) role = (threadIdx.x >> 6) == w ? (WINDOW ? role_map[w] : role_map_lean[w]) : role;
@@ -1247,6 +1304,7 @@ __global__ __launch_bounds__(1024) void enc_stage_kernel(const uint8_t* __restri
     else if (role == kRoleCommit) stage_commit<WINDOW>(n, table, lds3, lane);
     else if (role == kRoleHash) stage_hash<WINDOW>(src, avail, n, lds3, lane);
     else if (role == kRoleTwins) stage_twins<WINDOW>(n, lds3, lane);
+    else if (role == kRoleNear) stage_near<EXT, WINDOW>(n, lds3, lane);
     else if (role == kRoleMatch0 || role == kRoleMatch1) stage_match<EXT, WINDOW>(src, avail, n, table, lds3, lane, role == kRoleMatch1 ? 1u : 0u);
     else if (role == kRoleOrbit0 || role == kRoleOrbit1) stage_orbit<EXT, WINDOW>(n, lds3, lane, role == kRoleOrbit1 ? 1u : 0u);
     else if (role == kRoleEmit) stream_emitter<StageCfg>(src, avail, out, lds3, lane, b, sizes, status);
