@@ -109,5 +109,32 @@ int main(int argc, char **argv)
     printf("H0 hazards whose span does not change with the twin  %.3f (and the twin is the nearest %.3f)\n", (double)agree / tiles, (double)agree_nearest / tiles);
     printf("   of those: twin at least 64 back %.3f, twin in an earlier tile %.3f, both literal %.3f\n", (double)agree_far / tiles, (double)agree_prev / tiles, (double)agree_lit / tiles);
     printf("window t-1..t only: H0 %.3f  H1 %.3f\n", (double)h0w1 / tiles, (double)h1w1 / tiles);
+
+    // ORBIT's late classification (lanes whose only twins are in tile t-2): in how many tiles does it change any lane's span?
+    {
+        uint64_t tiles_with_only2 = 0, tiles_changed = 0, lanes_changed = 0, tiles_with_hit = 0;
+        for (uint32_t t = 3; t < (n >> 6); ++t) {
+            int any_only2 = 0, any_change = 0, any_hit = 0;
+            for (uint32_t p = t << 6; p < (t << 6) + 64; ++p) {
+                const uint32_t lo2 = (t << 6) - 128u, lo1 = (t << 6) - 64u;
+                int nearer = 0, vis2 = -1, has2 = 0;
+                for (uint32_t q = p - 1; q >= lo1; --q) if (hs[q] == hs[p]) { nearer = 1; break; }
+                if (nearer) continue;
+                for (uint32_t q = lo1 - 1; q >= lo2; --q) if (hs[q] == hs[p]) { has2 = 1; if (visited[q]) { vis2 = (int)q; break; } }
+                if (!has2) continue;
+                any_only2 = 1;
+                if (vis2 < 0) continue;
+                any_hit = 1;
+                uint32_t span0 = 1, span_t = 1;
+                for (uint32_t q = lo2 - 1; q + 65536u > p && q != 0xFFFFFFFFu; --q)
+                    if (hs[q] == hs[p] && visited[q]) { const uint32_t k = prefix(in + p, in + q, 16); if (k >= 4) span0 = k; break; }
+                { const uint32_t k = prefix(in + p, in + vis2, 16); if (k >= 4) span_t = k; }
+                if (span0 != span_t) { any_change = 1; ++lanes_changed; }
+            }
+            tiles_with_only2 += any_only2; tiles_changed += any_change; tiles_with_hit += any_hit;
+        }
+        printf("late classification: tiles with a lane whose only twins are in t-2 %.3f, with a visited one %.3f, where a span changes %.3f (%.3f lanes per tile)\n",
+               (double)tiles_with_only2 / tiles, (double)tiles_with_hit / tiles, (double)tiles_changed / tiles, (double)lanes_changed / tiles);
+    }
     return 0;
 }

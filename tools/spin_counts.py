@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Light instrumentation (make -C turbosqueeze_amd/csrc spins): unsuccessful polls per tile of every encoder wavefront of block 0, at
+production timing (one ds_add per spin).  A tight poll is ~100 cycles, a sleeping one ~150-200.  Experiment tool.
+  python tools/spin_counts.py [ext]"""
+import ctypes as C, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import turbosqueeze_amd as tsq
+from turbosqueeze_amd import api
+api.lib_path = lambda ab=False: os.path.join(ROOT, "turbosqueeze_amd", os.environ.get("TSQ_LIB", "libturbosqueeze_amd_spins.so"))
+api._libs.clear()
+L = api.lib()
+L.tsqa_debug_spins.argtypes = [C.c_void_p]
+ext = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+codec = tsq.DeviceCodec(0)
+src = torch.from_numpy(tsq.synth.text(10 ** 9, 1)).cuda()
+out = torch.empty(api.container_bound(src.numel()), dtype=torch.uint8, device="cuda")
+codec.profile(True)
+codec.compress(src, ext, out); codec.profile_read()
+for _ in range(3): codec.compress(src, ext, out)
+torch.cuda.synchronize()
+em, en, dm, dn = codec.profile_read()
+sp = np.zeros(16, dtype=np.uint32)
+assert L.tsqa_debug_spins(sp.ctypes.data) == 0
+tiles = (1 << 22) / 64
+names = ["WALK (orbit)", "ORBIT even", "ORBIT odd", "ACCOUNT", "NEAR", "MATCH even", "MATCH odd", "BUILDER", "-", "HASH", "TWINS", "EMIT", "WALK (answers)", "COMMIT", "-", "-"]
+print(f"encode kernel {em / max(en, 1):.2f} ms; unsuccessful polls per tile, block 0:")
+for w in range(16):
+    if names[w] != "-": print(f"  wave {w:2d} {names[w]:16s} {sp[w] / tiles:8.3f}")

@@ -123,6 +123,17 @@ __device__ __forceinline__ void stage_jitter(uint32_t salt)
 #define TSQ_JIT(salt) do {} while (0)
 #endif
 
+// Light instrumentation (-DTSQ_SPINS, make spins, tools/spin_counts.py): every unsuccessful poll of every wavefront is counted in
+// LDS (one ds_add per spin, nothing on the paths that do not wait), so that who waits for whom shows at production timing.
+#ifdef TSQ_SPINS
+__device__ uint32_t g_enc_spins[16];
+#define TSQ_SPIN(ctl) do { if ((threadIdx.x & 63u) == 0u) __hip_atomic_fetch_add(&(ctl)[48u + (threadIdx.x >> 6)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
+#define TSQ_SPIN_AT(ctl, slot) do { if ((threadIdx.x & 63u) == 0u) __hip_atomic_fetch_add(&(ctl)[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
+#else
+#define TSQ_SPIN(ctl) do {} while (0)
+#define TSQ_SPIN_AT(ctl, slot) do {} while (0)
+#endif
+
 // Consuming a record: the counter is read first, the record's words after it.  The LDS executes the DS operations of a
 // wavefront in program order (see stage_publish), so only the compiler has to be kept from hoisting record loads above
 // the counter load: the barrier below is the acquire half of the handshake at compiler level.
@@ -137,6 +148,7 @@ __device__ __forceinline__ bool stage_spin_tight(lds_u32_t* ctl, uint32_t word, 
     for (;;) {
         if (stage_ready(ctl, word, need)) return true;
         if (uniform(__hip_atomic_load(&ctl[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0u) return false;
+        TSQ_SPIN(ctl);
     }
 }
 __device__ __forceinline__ bool stage_spin(lds_u32_t* ctl, uint32_t word, uint32_t need)
@@ -144,6 +156,7 @@ __device__ __forceinline__ bool stage_spin(lds_u32_t* ctl, uint32_t word, uint32
     for (;;) {
         if (stage_ready(ctl, word, need)) return true;
         if (uniform(__hip_atomic_load(&ctl[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0u) return false;
+        TSQ_SPIN(ctl);
         __builtin_amdgcn_s_sleep(1);
     }
 }
@@ -156,6 +169,7 @@ __device__ __forceinline__ bool stage_spin_seen(lds_u32_t* ctl, uint32_t word, u
         asm volatile("" ::: "memory");
         if (seen >= need) return true;
         if (uniform(__hip_atomic_load(&ctl[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0u) return false;
+        TSQ_SPIN(ctl);
         __builtin_amdgcn_s_sleep(1);
     }
 }
@@ -797,7 +811,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
 #ifdef TSQ_STATS
                     const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
 #endif
-                    while (!stage_ready(ctl, orbit_word, t + 1u)) {}
+                    while (!stage_ready(ctl, orbit_word, t + 1u)) { TSQ_SPIN(ctl); }
 #ifdef TSQ_STATS
                     st_[8] += __builtin_amdgcn_s_memtime() - w0_;
 #endif
@@ -941,7 +955,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
 #ifdef TSQ_STATS
                     const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
 #endif
-                    while (!stage_ready(ctl, kCtlReplies, n_query)) {}
+                    while (!stage_ready(ctl, kCtlReplies, n_query)) { TSQ_SPIN_AT(ctl, 60u); }
 #ifdef TSQ_STATS
                     st_[10] += __builtin_amdgcn_s_memtime() - w0_;
 #endif
@@ -1099,7 +1113,7 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
 #ifdef TSQ_STATS
             const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
 #endif
-            while (!stage_ready(ctl, kCtlEvHead, ev_tail + 1u)) __builtin_amdgcn_s_sleep(1);
+            while (!stage_ready(ctl, kCtlEvHead, ev_tail + 1u)) { TSQ_SPIN(ctl); __builtin_amdgcn_s_sleep(1); }
 #ifdef TSQ_STATS
             st_[8] += __builtin_amdgcn_s_memtime() - w0_;
 #endif
@@ -1309,6 +1323,10 @@ __global__ __launch_bounds__(1024) void enc_stage_kernel(const uint8_t* __restri
     else if (role == kRoleOrbit0 || role == kRoleOrbit1) stage_orbit<EXT, WINDOW>(n, lds3, lane, role == kRoleOrbit1 ? 1u : 0u);
     else if (role == kRoleEmit) stream_emitter<StageCfg>(src, avail, out, lds3, lane, b, sizes, status);
     else if (role == kRoleBuilder) stream_builder<StageCfg>(lds3, lane);
+#ifdef TSQ_SPINS
+    if (blockIdx.x == 0 && lane == 0) g_enc_spins[threadIdx.x >> 6] = reinterpret_cast<uint32_t*>(stage_lds + StageCfg::off_ctl)[48u + (threadIdx.x >> 6)];
+    if (blockIdx.x == 0 && role == kRoleAccount && lane == 0) g_enc_spins[12] = reinterpret_cast<uint32_t*>(stage_lds + StageCfg::off_ctl)[60];   // (ACCOUNT leaves after WALK)
+#endif
 }
 
 }  // namespace tsq

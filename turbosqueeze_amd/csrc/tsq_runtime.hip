@@ -608,6 +608,12 @@ extern "C" int tsqa_measure_copy(tsqa_ctx* c, size_t bytes, int reps, double* be
     return rc;
 }
 
+#ifdef TSQ_SPINS
+extern "C" int tsqa_debug_spins(uint32_t* out16)
+{
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(tsq::g_enc_spins), 16 * sizeof(uint32_t)) == hipSuccess ? TSQA_OK : TSQA_ERR_HIP;
+}
+#endif
 #ifdef TSQ_STATS
 // instrumented builds only: counters published by block 0 of the last encode / decode launch
 extern "C" int tsqa_debug_stats(unsigned long long* enc64, unsigned long long* dec16)
