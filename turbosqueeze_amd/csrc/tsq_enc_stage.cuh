@@ -697,6 +697,13 @@ __device__ __forceinline__ uint32_t s_sel(uint32_t c, uint32_t a, uint32_t b)
 { uint32_t d; asm("s_cmp_lg_u32 %1, 0\n\ts_cselect_b32 %0, %2, %3" : "=s"(d) : "s"(c), "s"(a), "s"(b) : "scc"); return d; }
 __device__ __forceinline__ uint64_t s_sel64(uint32_t c, uint64_t a, uint64_t b)
 { uint64_t d; asm("s_cmp_lg_u32 %1, 0\n\ts_cselect_b64 %0, %2, %3" : "=s"(d) : "s"(c), "s"(a), "s"(b) : "scc"); return d; }
+// two selects on one condition (one s_cmp), and selects straight on "x != 0" (no 0/1 flag in between)
+__device__ __forceinline__ void s_sel_64_32(uint32_t c, uint64_t a1, uint64_t b1, uint32_t a2, uint32_t b2, uint64_t& d1, uint32_t& d2)
+{ asm("s_cmp_lg_u32 %2, 0\n\ts_cselect_b64 %0, %3, %4\n\ts_cselect_b32 %1, %5, %6" : "=&s"(d1), "=&s"(d2) : "s"(c), "s"(a1), "s"(b1), "s"(a2), "s"(b2) : "scc"); }
+__device__ __forceinline__ void s_selnz64_64_32(uint64_t x, uint64_t a1, uint64_t b1, uint32_t a2, uint32_t b2, uint64_t& d1, uint32_t& d2)
+{ asm("s_cmp_lg_u64 %2, 0\n\ts_cselect_b64 %0, %3, %4\n\ts_cselect_b32 %1, %5, %6" : "=&s"(d1), "=&s"(d2) : "s"(x), "s"(a1), "s"(b1), "s"(a2), "s"(b2) : "scc"); }
+__device__ __forceinline__ uint32_t s_selnz64(uint64_t x, uint32_t a, uint32_t b)
+{ uint32_t d; asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, %2, %3" : "=s"(d) : "s"(x), "s"(a), "s"(b) : "scc"); return d; }
 __device__ __forceinline__ uint32_t s_nz64(uint64_t x)
 { uint32_t d; asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(d) : "s"(x) : "scc"); return d; }
 __device__ __forceinline__ uint32_t s_nz(uint32_t x)
@@ -840,8 +847,8 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                 // the orbit from L0: halts on a hard lane or past the tile (nothing at all if L0 itself is hard)
                 const uint32_t o_lo = rdlane(orb_lo, L0), o_hi = rdlane(orb_hi, L0), o_nx = rdlane(nx, L0);
                 const uint32_t entry_ok = ((uint32_t)(hard >> L0) & 1u) ^ 1u;
-                uint64_t V = s_sel64(entry_ok, (uint64_t)o_lo | ((uint64_t)o_hi << 32), 0ull);
-                L = s_sel(entry_ok, o_nx & 0x7Fu, L0);
+                uint64_t V;
+                s_sel_64_32(entry_ok, (uint64_t)o_lo | ((uint64_t)o_hi << 32), 0ull, o_nx & 0x7Fu, L0, V, L);
                 // the orbit treated twin lanes as ordinary lanes.  That is wrong for a visited lane that has a VISITED
                 // twin before it (earlier in this tile, or in the two previous tiles): its gathered candidate is not
                 // current.  The first such lane ends the segment; everything before it is exact.
@@ -861,18 +868,16 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                     bad = ((bad & ~near_m) | (near_m & ~__ballot(near_visited))) & V;
                 }
                 {
-                    const uint32_t trunc = s_nz64(bad);
                     const uint32_t Lb = s_lsb64(bad | (1ull << 63));
-                    V = s_sel64(trunc, V & ((1ull << Lb) - 1ull), V);
-                    L = s_sel(trunc, Lb, L);
-                    TSQ_CNT(23, trunc);
+                    s_selnz64_64_32(bad, V & ((1ull << Lb) - 1ull), V, Lb, L, V, L);
+                    TSQ_CNT(23, bad != 0ull ? 1 : 0);
                 }
                 TSQ_CNT(24, 1);
                 REG_END(2);
                 REG_BEGIN(3);
                 {
                     const uint64_t M = V & certain_m;
-                    last_m = s_sel(s_nz64(M), base + s_msb64(M | 1ull), last_m);
+                    last_m = s_selnz64(M, base + s_msb64(M | 1ull), last_m);
                 }
                 Vacc |= V;
                 vall |= V;
@@ -882,10 +887,21 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                 TSQ_CNT(26, 1); TSQ_CNT(27, ((hard >> L) & 1ull) ? 1 : 0);
                 // ---- one hazard lane (hard, or with a visited twin): its candidate and common prefix
                 const uint32_t i = base + L;
-                uint32_t cand = rdlane(cand0, L);
-                uint32_t k = rdlane(k0, L);
-                uint32_t twin_cand = 0;
-                {
+                uint32_t cand, k, twin_cand;
+                // The lane's nearest twin, with the common prefix, is in NEAR's word.  If that twin was visited it IS the candidate
+                // (the most recent visited position with the lane's hash): five hazard lanes out of six, one readlane and a bit test.
+                const uint32_t nw = rdlane(nearw, L);
+                const uint32_t nback = (nw >> 12) & 3u, nq = (nw >> 6) & 63u;
+                const uint64_t nmask = s_sel64(nback, s_sel64(nback & 2u, vall_p2, vall_p1), vall);
+                if ((nw >> 15) & (uint32_t)(nmask >> nq) & 1u) {
+                    cand = base - (nback << 6) + nq;
+                    k = nw & 63u;
+                    twin_cand = 1;
+                    TSQ_CNT(16, 1);
+                } else {
+                    cand = rdlane(cand0, L);
+                    k = rdlane(k0, L);
+                    twin_cand = 0;
                     // visited twins of lane L: in this tile (before L) and in the two previous tiles;
                     // the most recent one is the candidate
                     const uint64_t in_tile = ((uint64_t)rdlane(tin_lo, L) | ((uint64_t)rdlane(tin_hi, L) << 32)) & vall;
@@ -896,14 +912,9 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                         const uint32_t back = in_tile ? 0u : in_p1 ? 64u : 128u;
                         const uint32_t pick_lane = msb64(pick);
                         cand = base - back + pick_lane;
-                        // the nearest twin's prefix is there already (NEAR); another twin's is taken from the tile records
-                        const uint32_t nw = rdlane(nearw, L);
-                        if (nw == (0x8000u | (back << 6) | (pick_lane << 6) | (nw & 63u))) { k = nw & 63u; TSQ_CNT(16, 1); }
-                        else {
-                            const uint32_t tiles_back = back >> 6;
-                            const uint32_t cand_slot = rec_slot >= tiles_back ? rec_slot - tiles_back : rec_slot + StageCfg::R - tiles_back;
-                            k = uniform(prefix16(words_at(rec_slot, i), words_at(cand_slot, cand)));
-                        }
+                        const uint32_t tiles_back = back >> 6;
+                        const uint32_t cand_slot = rec_slot >= tiles_back ? rec_slot - tiles_back : rec_slot + StageCfg::R - tiles_back;
+                        k = uniform(prefix16(words_at(rec_slot, i), words_at(cand_slot, cand)));
                         twin_cand = 1;
                         TSQ_CNT(17, in_tile ? 1 : 0); TSQ_CNT(18, (!in_tile && in_p1) ? 1 : 0); TSQ_CNT(19, (!in_tile && !in_p1) ? 1 : 0);
                         if (EXT && k >= 16u) {
@@ -942,9 +953,9 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                 const uint32_t local = s_ge(last_m, cand + need) & s_lt(i, tail_from) & s_lt(i - cand, 0xFF00u);
                 if (local) {
                     ev_push(kEvHaz, i, cand, k | (twin_cand << 8) | (1u << 9));
-                    const uint32_t m = length_nibble(need);
                     const uint32_t is_m = s_ge(k, 4u);
-                    v = s_sel(is_m, i + nibble_span(m), i + 1u);
+                    // (without extensions a match of k <= 16 bytes advances by k: mlen[k] = k - 1, tsq_encode.cpp:44-45,154)
+                    v = s_sel(is_m, i + (EXT ? nibble_span(length_nibble(need)) : need), i + 1u);
                     last_m = s_sel(is_m, i, last_m);
                     Vacc |= 1ull << L;
                 } else {
@@ -999,7 +1010,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
 // All symbol state lives in uniform 32-bit integers (flags as 0/1, not bool: a bool that crosses a branch
 // becomes a 64-bit lane mask and costs VALU round trips), and the common paths are straight-line selects:
 // for a single wavefront a uniform branch costs more than the few instructions it skips.
-template <bool WINDOW>
+template <bool EXT, bool WINDOW>
 __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_t lane)
 {
     using StageCfg = StageCfgT<WINDOW>;
@@ -1186,9 +1197,10 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
             if (is_query == 0u) {
                 // ---- a hazard lane WALK has decided: it joins the tile's masks like a certain lane
                 const uint32_t is_m = s_ge(k, 4u);
-                const uint32_t m = length_nibble(k < 4u ? 4u : k);
+                const uint32_t k4 = k < 4u ? 4u : k;
+                const uint32_t m = EXT ? length_nibble(k4) : k4 - 1u;          // (mlen[k] = k - 1 up to 16, tsq_encode.cpp:44-45)
                 certain_m = s_sel64(is_m, certain_m | bit, certain_m & ~bit);
-                const uint32_t sp = s_sel(is_m, nibble_span(m), 1u);
+                const uint32_t sp = s_sel(is_m, EXT ? nibble_span(m) : k4, 1u);
                 span_nat = lane == L ? sp : span_nat;
                 lw = lane == L ? (cand | (m << 24)) : lw;
                 TSQ_CNT(21, is_m);
@@ -1314,7 +1326,7 @@ __global__ __launch_bounds__(1024) void enc_stage_kernel(const uint8_t* __restri
     if (blockIdx.x == 0 && lane == 0) { uint32_t id; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id)); g_enc_trace[15 * 256 + (threadIdx.x >> 6)] = id; }
 #endif
     if (role == kRoleWalk) stage_walk<EXT, WINDOW>(src, avail, n, lds3, lane);
-    else if (role == kRoleAccount) stage_account<WINDOW>(n, lds3, lane);
+    else if (role == kRoleAccount) stage_account<EXT, WINDOW>(n, lds3, lane);
     else if (role == kRoleCommit) stage_commit<WINDOW>(n, table, lds3, lane);
     else if (role == kRoleHash) stage_hash<WINDOW>(src, avail, n, lds3, lane);
     else if (role == kRoleTwins) stage_twins<WINDOW>(n, lds3, lane);
