@@ -59,7 +59,7 @@ cases = [
     ("tiny 1", np.frombuffer(b"A", dtype=np.uint8).copy()),
     ("tiny 44", np.frombuffer(b"abcdefgh_abcdefgh_abcdefgh_XYZ_abcdefgh_abcd", dtype=np.uint8).copy()),
 ]
-for s in range(3 if "--enc-only" in sys.argv else 12):
+for s in range(3 if ("--enc-only" in sys.argv or "--dec-only" in sys.argv) else 12):
     cases.append((f"fuzz {s}", np.ascontiguousarray(fuzzgen.structured(np.random.default_rng(100 + s), int(rng.integers(1, 700000))))))
 for name, host in cases:
     for ext in (0, 1):
@@ -72,7 +72,7 @@ if "--no-time" not in sys.argv:
     src = torch.from_numpy(host).cuda()
     out = torch.empty(api.container_bound(len(host)), dtype=torch.uint8, device="cuda")
     codec.profile(True)
-    for ext in ((0,) if "--enc-only" in sys.argv else (0, 1)):
+    for ext in ((0,) if ("--enc-only" in sys.argv or "--dec-only" in sys.argv) else (0, 1)):
         blob = codec.compress(src, ext, out)
         back = codec.decompress(blob)
         codec.profile_read()
@@ -85,7 +85,7 @@ if "--no-time" not in sys.argv:
         print(f"TIME text 1e9 ext={ext}: encode kernel {em / max(en, 1):.2f} ms, decode kernel {dm / max(dn, 1):.3f} ms, ratio {blob.numel() / len(host):.4f}", flush=True)
 if "--no-time" not in sys.argv and "--enc-only" not in sys.argv:
     # few blocks: one workgroup per block (variant 4), PARSE + COPY (6), two PARSE + COPY where the CUs allow (3)
-    for nb in (30, 60, 120):
+    for nb in ((60,) if "--dec-only" in sys.argv else (30, 60, 120)):
         host = tsq.synth.text(nb * B, 2)
         src = torch.from_numpy(host).cuda()
         blob = codec.compress(src, 0)

@@ -21,10 +21,16 @@ codec.compress(src, ext, out); codec.profile_read()
 for _ in range(3): codec.compress(src, ext, out)
 torch.cuda.synchronize()
 em, en, dm, dn = codec.profile_read()
-sp = np.zeros(16, dtype=np.uint32)
+sp = np.zeros(20, dtype=np.uint32)
 assert L.tsqa_debug_spins(sp.ctypes.data) == 0
 tiles = (1 << 22) / 64
-names = ["WALK (orbit)", "ORBIT even", "ORBIT odd", "ACCOUNT", "NEAR", "MATCH even", "MATCH odd", "BUILDER", "-", "HASH", "TWINS", "EMIT", "WALK (answers)", "COMMIT", "-", "-"]
+import re
+src_ = open(os.path.join(ROOT, "turbosqueeze_amd", "csrc", "tsq_enc_stage.cuh")).read()
+mm = re.search(r"#define TSQ_X_MAP (\d+)", src_)
+pat = r"#(?:el)?if TSQ_X_MAP == %s\b[^\n]*\n\s*constexpr uint32_t role_map\[16\] = \{([^}]*)\}" % mm.group(1) if mm else r"constexpr uint32_t role_map\[16\] = \{([^}]*)\}"
+names = [x.strip().replace("kRole", "") for x in re.search(pat, src_).group(1).split(",")]
+extra = ["WALK waits for answers", "ACCOUNT waits for BUILDER (queue full)", "WALK waits for ACCOUNT (events full)", "BUILDER waits for EMIT (ring full)"]
 print(f"encode kernel {em / max(en, 1):.2f} ms; unsuccessful polls per tile, block 0:")
 for w in range(16):
-    if names[w] != "-": print(f"  wave {w:2d} {names[w]:16s} {sp[w] / tiles:8.3f}")
+    if names[w] != "None": print(f"  wave {w:2d} {names[w]:16s} {sp[w] / tiles:8.3f}")
+for q in range(4): print(f"  {extra[q]:44s} {sp[16 + q] / tiles:8.3f}")

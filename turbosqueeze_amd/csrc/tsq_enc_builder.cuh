@@ -144,12 +144,13 @@ __device__ __forceinline__ void stream_builder(lds_u8_t* lds, uint32_t lane)
 #ifdef TSQ_STATS
             const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
 #endif
-            while (__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == tail) __builtin_amdgcn_s_sleep(1);
+            while (__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == tail) { TSQ_SPIN(ctl); __builtin_amdgcn_s_sleep(1); }
 #ifdef TSQ_STATS
             st_[17] += __builtin_amdgcn_s_memtime() - w0_;
 #endif
         }
         volatile lds_u32_t* it = queue + (tail % Cfg::Q) * Cfg::ITEM_WORDS;
+        TSQ_DELAY(8);
         const uint32_t kind = uniform(it[0]);
         const uint32_t nsym_entry = uniform(it[4]);
         uint32_t nsym_after = nsym_entry;
@@ -161,6 +162,7 @@ __device__ __forceinline__ void stream_builder(lds_u8_t* lds, uint32_t lane)
             for (;;) {
                 batches_seen = uniform(__hip_atomic_load(&ctl[kCtlBatches], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 if (nsym_entry + 66u - 64u * batches_seen <= Cfg::RING) break;
+                TSQ_SPIN_AT(ctl, 47u);
                 __builtin_amdgcn_s_sleep(2);
             }
 #ifdef TSQ_STATS
@@ -266,6 +268,7 @@ __device__ __forceinline__ void stream_emitter(const uint8_t* src, uint64_t avai
         asm volatile("" ::: "memory");
         if (have >= 64u * (batches + 1u)) {
             flush_batch(64u * batches, 64u);
+            TSQ_DELAY(9);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the records are read: the ring entries may be reused
             batches++;
             if (lane == 0) __hip_atomic_store(&ctl[kCtlBatches], batches, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -275,6 +278,7 @@ __device__ __forceinline__ void stream_emitter(const uint8_t* src, uint64_t avai
 #ifdef TSQ_STATS
         const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
 #endif
+        TSQ_SPIN(ctl);
         __builtin_amdgcn_s_sleep(8);
 #ifdef TSQ_STATS
         waited_ += __builtin_amdgcn_s_memtime() - w0_;

@@ -123,17 +123,6 @@ __device__ __forceinline__ void stage_jitter(uint32_t salt)
 #define TSQ_JIT(salt) do {} while (0)
 #endif
 
-// Light instrumentation (-DTSQ_SPINS, make spins, tools/spin_counts.py): every unsuccessful poll of every wavefront is counted in
-// LDS (one ds_add per spin, nothing on the paths that do not wait), so that who waits for whom shows at production timing.
-#ifdef TSQ_SPINS
-__device__ uint32_t g_enc_spins[16];
-#define TSQ_SPIN(ctl) do { if ((threadIdx.x & 63u) == 0u) __hip_atomic_fetch_add(&(ctl)[48u + (threadIdx.x >> 6)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
-#define TSQ_SPIN_AT(ctl, slot) do { if ((threadIdx.x & 63u) == 0u) __hip_atomic_fetch_add(&(ctl)[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
-#else
-#define TSQ_SPIN(ctl) do {} while (0)
-#define TSQ_SPIN_AT(ctl, slot) do {} while (0)
-#endif
-
 // Consuming a record: the counter is read first, the record's words after it.  The LDS executes the DS operations of a
 // wavefront in program order (see stage_publish), so only the compiler has to be kept from hoisting record loads above
 // the counter load: the barrier below is the acquire half of the handshake at compiler level.
@@ -218,17 +207,22 @@ __device__ __forceinline__ void stage_hash(const uint8_t* src, uint64_t avail, u
     unsigned long long st_[32] = {0};
 #endif
     TSQ_BEGIN();
-    uint4 w_next = ld128z(src, lane, avail);
-    for (uint32_t t = 0; t < n_tiles; ++t) {
+    // The input words are requested D tiles ahead: every other tile starts a new 128-byte line that comes from HBM (two microseconds,
+    // more than a tile period), and this wavefront feeds every other stage.
+#ifndef TSQ_X_HD
+#define TSQ_X_HD 4
+#endif
+    constexpr uint32_t D = TSQ_X_HD;                     // tiles the input words are requested ahead
+    uint4 w_q[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; ++d) w_q[d] = ld128z(src, (uint64_t)lane + 64u * d, avail);
+    auto one_tile = [&](uint32_t t, const uint4 w16) -> bool {
         // the slot of tile t-R is free once WALK has finished tile t-R+2 (it reads the words of two tiles back) and ACCOUNT and
         // COMMIT are past tile t-R
-        if (t + 3u > StageCfg::R && !stage_wait_seen(ctl, 5, t + 3u - StageCfg::R, parsed_seen, 0)) break;
-        if (t + 1u > StageCfg::R && !stage_wait_seen(ctl, kCtlAccounted, t + 1u - StageCfg::R, accounted_seen, 0)) break;
-        if (t + 1u > StageCfg::R && !stage_wait_seen(ctl, kCtlCommitted, t + 1u - StageCfg::R, committed_seen, 0)) break;
+        if (t + 3u > StageCfg::R && !stage_wait_seen(ctl, 5, t + 3u - StageCfg::R, parsed_seen, 0)) return false;
+        if (t + 1u > StageCfg::R && !stage_wait_seen(ctl, kCtlAccounted, t + 1u - StageCfg::R, accounted_seen, 0)) return false;
+        if (t + 1u > StageCfg::R && !stage_wait_seen(ctl, kCtlCommitted, t + 1u - StageCfg::R, committed_seen, 0)) return false;
         TSQ_TRACE(0, t);
-        const uint32_t p = (t << 6) + lane;
-        const uint4 w16 = w_next;
-        w_next = ld128z(src, (uint64_t)p + 64u, avail);    // the next tile's words: this wave's only global access, a full iteration ahead
         const uint32_t h = hash4(w16.x);
         const uint32_t hf = h & StageCfg::OWN_MASK;
         const uint32_t tag = (id << 6) | lane;          // never 0: the image starts zeroed
@@ -252,10 +246,25 @@ __device__ __forceinline__ void stage_hash(const uint8_t* src, uint64_t avail, u
         arr[kAH * 64] = h;
         arr[kAOwn * 64] = before | (id << 8) | (after != tag ? 0x1000u : 0u);     // owner before | this tile's id | another lane of the tile took the bucket
         TSQ_TRACE(1, t);
+        TSQ_DELAY(0);
         stage_publish(ctl, kCtlHashed, t + 1u, lane);
         hf_m3 = hf_m2; hf_m2 = hf_m1; hf_m1 = hf;
         id = id == 3u ? 1u : id + 1u;
         wbase = wbase + 64u == StageCfg::WIN ? 0u : wbase + 64u;
+        return true;
+    };
+    // (unrolled by hand so that the queue of requested words stays in fixed registers)
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += D) {
+        bool go = true;
+#pragma unroll
+        for (uint32_t d = 0; d < D; ++d) {
+            const uint32_t t = t0 + d;
+            if (go && t < n_tiles) {
+                go = one_tile(t, w_q[d]);
+                w_q[d] = ld128z(src, (uint64_t)(t + D) * 64u + lane, avail);      // this wave's only global access
+            }
+        }
+        if (!go) break;
     }
 #ifdef TSQ_STATS
     if (blockIdx.x == 0 && lane == 0) { g_enc_stats[0] = st_[0]; g_enc_stats[1] = TSQ_TOTAL(); }
@@ -342,6 +351,7 @@ __device__ __forceinline__ void stage_twins(uint32_t n, lds_u8_t* lds, uint32_t 
         arr[kATp2 * 64] = (uint32_t)twin_p2;  arr[(kATp2 + 1) * 64] = (uint32_t)(twin_p2 >> 32);
         arr[kATp3 * 64] = (uint32_t)twin_p3;  arr[(kATp3 + 1) * 64] = (uint32_t)(twin_p3 >> 32);
         TSQ_TRACE(2, t);
+        TSQ_DELAY(1);
         stage_publish(ctl, 2, t + 1u, lane);
         h_m3 = h_m2; h_m2 = h_m1; h_m1 = h;
     }
@@ -389,6 +399,7 @@ __device__ __forceinline__ void stage_near(uint32_t n, lds_u8_t* lds, uint32_t l
             if ((in0 || in1 || in2) && !(EXT && k >= 16u)) word = 0x8000u | (back << 12) | (q << 6) | k;
         }
         arr[kAOwn * 64] = word;
+        TSQ_DELAY(2);
         stage_publish(ctl, kCtlNear, t + 1u, lane);
     }
 #ifdef TSQ_STATS
@@ -532,6 +543,7 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         if (t >= 3u) { st_[24] += (uint32_t)((uint32_t)__builtin_amdgcn_s_memtime() - uniform(ctl[40u + ((t - 3u) & 7u)])); st_[25] += 1; }
 #endif
         TSQ_TRACE(5, t);
+        TSQ_DELAY(3);
         stage_publish(ctl, parity ? kCtlMatchedOdd : 3u, t + 1u, lane);
         MREG_END(14);
         wbase = wbase + 128u >= StageCfg::WIN ? wbase + 128u - StageCfg::WIN : wbase + 128u;
@@ -579,6 +591,7 @@ __device__ __forceinline__ void stage_commit(uint32_t n, uint16_t* table, lds_u8
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the table stores are complete
         TSQ_TRACE(6, t);
+        TSQ_DELAY(4);
         stage_publish(ctl, kCtlCommitted, t + 1u, lane);
     }
 #ifdef TSQ_STATS
@@ -683,6 +696,7 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
         if (t >= 3u) { st_[24] += (uint32_t)((uint32_t)__builtin_amdgcn_s_memtime() - uniform(ctl[40u + ((t - 3u) & 7u)])); st_[25] += 1; }
 #endif
         TSQ_TRACE(7, t);
+        TSQ_DELAY(5);
         stage_publish(ctl, parity ? kCtlOrbitOdd : 4u, t + 1u, lane);
     }
 #ifdef TSQ_STATS
@@ -759,7 +773,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
 #endif
         while (ev_head - ev_tail_seen >= StageCfg::EQ) {
             ev_tail_seen = uniform(__hip_atomic_load(&ctl[kCtlEvTail], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            if (ev_head - ev_tail_seen >= StageCfg::EQ) __builtin_amdgcn_s_sleep(1);
+            if (ev_head - ev_tail_seen >= StageCfg::EQ) { TSQ_SPIN_AT(ctl, 46u); __builtin_amdgcn_s_sleep(1); }
         }
 #ifdef TSQ_STATS
         st_[9] += __builtin_amdgcn_s_memtime() - w0_;
@@ -952,10 +966,17 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                 const uint32_t need = k < 4u ? 4u : k;
                 const uint32_t local = s_ge(last_m, cand + need) & s_lt(i, tail_from) & s_lt(i - cand, 0xFF00u);
                 if (local) {
-                    ev_push(kEvHaz, i, cand, k | (twin_cand << 8) | (1u << 9));
+                    // the lane's class goes straight into the tile's record: ACCOUNT reads the record when the segment that holds the
+                    // lane arrives (no event of its own: ACCOUNT is the busiest wavefront of the pipeline)
                     const uint32_t is_m = s_ge(k, 4u);
                     // (without extensions a match of k <= 16 bytes advances by k: mlen[k] = k - 1, tsq_encode.cpp:44-45,154)
-                    v = s_sel(is_m, i + (EXT ? nibble_span(length_nibble(need)) : need), i + 1u);
+                    const uint32_t m = EXT ? length_nibble(need) : need - 1u;
+                    const uint32_t sp = s_sel(is_m, EXT ? nibble_span(m) : need, 1u);
+                    if (lane == L) {
+                        arr[kASpan * 64] = (spanword & ~0x4FFu) | sp | (is_m << 10);
+                        arr[kALane * 64] = cand | (m << 24);
+                    }
+                    v = i + sp;
                     last_m = s_sel(is_m, i, last_m);
                     Vacc |= 1ull << L;
                 } else {
@@ -966,7 +987,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
 #ifdef TSQ_STATS
                     const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
 #endif
-                    while (!stage_ready(ctl, kCtlReplies, n_query)) { TSQ_SPIN_AT(ctl, 60u); }
+                    while (!stage_ready(ctl, kCtlReplies, n_query)) { TSQ_SPIN_AT(ctl, 44u); }
 #ifdef TSQ_STATS
                     st_[10] += __builtin_amdgcn_s_memtime() - w0_;
 #endif
@@ -991,6 +1012,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
             lds_u32_t* vis = (lds_u32_t*)(recs + rec_slot * StageCfg::REC_WORDS + 2u);
             if (lane < 2u) __hip_atomic_store(&vis[lane], lane ? (uint32_t)(vall >> 32) : (uint32_t)vall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        TSQ_DELAY(6);
         stage_publish(ctl, 5, t + 1u, lane);
         if (Vtail != 0ull) ev_push(kEvSeg, base, (uint32_t)Vtail, (uint32_t)(Vtail >> 32));
 #ifdef TSQ_STATS
@@ -1035,7 +1057,7 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
 #endif
             while (head - tail_seen >= StageCfg::Q) {
                 tail_seen = uniform(__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                if (head - tail_seen >= StageCfg::Q) __builtin_amdgcn_s_sleep(2);
+                if (head - tail_seen >= StageCfg::Q) { TSQ_SPIN_AT(ctl, 45u); __builtin_amdgcn_s_sleep(2); }
             }
 #ifdef TSQ_STATS
             st_[9] += __builtin_amdgcn_s_memtime() - w0_;
@@ -1066,7 +1088,7 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
     // from the masks.  Hazard lanes patch the masks; only the rare outcomes the masks cannot
     // express (a literal closed in front of a match that then fails, the block tail) are pushed explicitly,
     // after flushing what is pending.
-    uint64_t Vt = 0, Mt = 0;
+    uint64_t Vt = 0, Mt = 0, qmask = 0;        // qmask: the lanes of the tile a query decided
     uint32_t e_nsym = 0, e_origin = 0, e_lit_from = 0;
     auto flush_pending = [&]() {
         if (Vt != 0ull) {
@@ -1120,38 +1142,49 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
 
     TSQ_BEGIN();
     for (;;) {
-        if (!stage_ready(ctl, kCtlEvHead, ev_tail + 1u)) {
-#ifdef TSQ_STATS
-            const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
-#endif
-            while (!stage_ready(ctl, kCtlEvHead, ev_tail + 1u)) { TSQ_SPIN(ctl); __builtin_amdgcn_s_sleep(1); }
-#ifdef TSQ_STATS
-            st_[8] += __builtin_amdgcn_s_memtime() - w0_;
-#endif
-        }
         uint32_t kind, ea, eb, ec;
         {
+            // the producer's counter and the event's words are requested together (the LDS serves a wavefront's requests in order: if
+            // the counter says the event is there, the words behind it are the event's): ACCOUNT is the busiest wavefront of the
+            // pipeline, and this is one LDS round trip per event less
             volatile lds_u32_t* e = evq + (ev_tail % StageCfg::EQ) * StageCfg::EV_WORDS;
-            const uint32_t w = e[lane & 3u];
+            const uint32_t hv = ((volatile lds_u32_t*)ctl)[kCtlEvHead];
+            uint32_t w = e[lane & 3u];
+            asm volatile("" ::: "memory");
+            if (uniform(hv) < ev_tail + 1u) {
+#ifdef TSQ_STATS
+                const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
+#endif
+                while (!stage_ready(ctl, kCtlEvHead, ev_tail + 1u)) { TSQ_SPIN(ctl); __builtin_amdgcn_s_sleep(1); }
+#ifdef TSQ_STATS
+                st_[8] += __builtin_amdgcn_s_memtime() - w0_;
+#endif
+                w = e[lane & 3u];
+            }
             kind = rdlane(w, 0); ea = rdlane(w, 1); eb = rdlane(w, 2); ec = rdlane(w, 3);
             ev_tail++;
             __hip_atomic_store(&ctl[kCtlEvTail], ev_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (kind == kEvEnd) break;
         const uint32_t ev_base = ea & ~63u;
-        if (ev_base != base) {
-            // ---- a new tile: what is pending goes to the builder, then the tile's record
-            flush_pending();
+        const uint32_t new_tile = ev_base != base ? 1u : 0u;
+        if (new_tile | (kind == kEvSeg ? 1u : 0u)) {
+            // ---- a new tile: what is pending goes to the builder, then the tile's record.  (A later segment of a tile that a query
+            //      opened reads the record again: WALK patches the hazard lanes it decides itself into the class words, and it has
+            //      done so for every lane of a segment before the segment's event.)
+            if (new_tile) { flush_pending(); qmask = 0; }
             base = ev_base;
             const uint32_t t = base >> 6;
             volatile lds_u32_t* arr = recs + (t % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::ARR + lane;
             const uint32_t spanword = arr[kASpan * 64];
-            lw = arr[kALane * 64];
+            const uint32_t fresh_lw = arr[kALane * 64];
+            lw = ((qmask >> lane) & 1ull) ? lw : fresh_lw;            // (a lane a query decided keeps the candidate ACCOUNT gave it)
             span_nat = spanword & 0xFFu;
             certain_m = __ballot((spanword & 0x400u) != 0u);
             // (SCAN may reuse the records of the tiles before this one)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __hip_atomic_store(&ctl[kCtlAccounted], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            TSQ_DELAY(7);
             TSQ_CNT(15, 1);
         }
         {
@@ -1191,21 +1224,9 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
         } else {
             const uint32_t i = ea, cand = eb;
             uint32_t k = ec & 0xFFu;
-            const uint32_t is_query = ((ec >> 9) & 1u) ^ 1u;
             const uint32_t L = i - base;
             const uint64_t bit = 1ull << L;
-            if (is_query == 0u) {
-                // ---- a hazard lane WALK has decided: it joins the tile's masks like a certain lane
-                const uint32_t is_m = s_ge(k, 4u);
-                const uint32_t k4 = k < 4u ? 4u : k;
-                const uint32_t m = EXT ? length_nibble(k4) : k4 - 1u;          // (mlen[k] = k - 1 up to 16, tsq_encode.cpp:44-45)
-                certain_m = s_sel64(is_m, certain_m | bit, certain_m & ~bit);
-                const uint32_t sp = s_sel(is_m, EXT ? nibble_span(m) : k4, 1u);
-                span_nat = lane == L ? sp : span_nat;
-                lw = lane == L ? (cand | (m << 24)) : lw;
-                TSQ_CNT(21, is_m);
-                continue;
-            }
+            qmask |= bit;
             // ---- exact scalar resolution of one hazard lane (hard, or with a visited twin)
             uint32_t v = i + 1u, done = 0;
             const uint32_t e4 = s_ge(k, 4u);
@@ -1261,12 +1282,10 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
                     v = ni;
                 }
             }
-            if (is_query) {
-                __hip_atomic_store(&ctl[kCtlReplyValue], v | (done << 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                TSQ_LDS_RELEASE();
-                n_reply++;
-                __hip_atomic_store(&ctl[kCtlReplies], n_reply, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            __hip_atomic_store(&ctl[kCtlReplyValue], v | (done << 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            TSQ_LDS_RELEASE();
+            n_reply++;
+            __hip_atomic_store(&ctl[kCtlReplies], n_reply, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     flush_pending();
@@ -1294,8 +1313,43 @@ __global__ __launch_bounds__(1024) void enc_stage_kernel(const uint8_t* __restri
     // (measured and dropped: s_setprio on the lag loop's stages or on WALK, COMMIT / EMIT / HASH on SIMD 0, NEAR on SIMD 2 or 3: all within 0.3 %)
     enum : uint32_t { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNone, kRoleMatch0, kRoleMatch1, kRoleBuilder, kRoleHash, kRoleTwins, kRoleEmit, kRoleCommit, kRoleNear };
     // (the lean layout -- two workgroups per CU -- launches the twelve working wavefronts only: 2 x 16 do not fit a CU's wave slots)
+#ifndef TSQ_X_MAP
+#define TSQ_X_MAP 6
+#endif
+#if TSQ_X_MAP == 0
     constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleBuilder,
                                         kRoleNone, kRoleHash, kRoleTwins, kRoleEmit, kRoleNone, kRoleCommit, kRoleNone, kRoleNone };
+#elif TSQ_X_MAP == 1   // SIMD 0: WALK, ACCOUNT;  SIMD 3: NEAR, BUILDER, EMIT
+    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleNear, kRoleAccount, kRoleMatch0, kRoleMatch1, kRoleBuilder,
+                                        kRoleNone, kRoleHash, kRoleTwins, kRoleEmit, kRoleNone, kRoleCommit, kRoleNone, kRoleNone };
+#elif TSQ_X_MAP == 2   // SIMD 0: WALK, NEAR, ACCOUNT;  SIMD 3: BUILDER, EMIT
+    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleNone, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleBuilder,
+                                        kRoleAccount, kRoleHash, kRoleTwins, kRoleEmit, kRoleNone, kRoleCommit, kRoleNone, kRoleNone };
+#elif TSQ_X_MAP == 3   // SIMD 0: WALK, NEAR;  SIMD 1: ORBIT0, MATCH0, HASH;  SIMD 2: ORBIT1, MATCH1, TWINS;  SIMD 3: ACCOUNT, BUILDER, EMIT, COMMIT
+    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleBuilder,
+                                        kRoleNone, kRoleHash, kRoleTwins, kRoleEmit, kRoleNone, kRoleNone, kRoleNone, kRoleCommit };
+#elif TSQ_X_MAP == 4   // SIMD 0: WALK, NEAR, COMMIT;  SIMD 1: ORBIT0, MATCH0, HASH
+    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleBuilder,
+                                        kRoleCommit, kRoleHash, kRoleTwins, kRoleEmit, kRoleNone, kRoleNone, kRoleNone, kRoleNone };
+#elif TSQ_X_MAP == 6   // SIMD 0: WALK, NEAR; SIMD 1: ORBIT0, MATCH0, HASH, BUILDER; SIMD 2: ORBIT1, MATCH1, TWINS, EMIT; SIMD 3: ACCOUNT, COMMIT
+    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleCommit,
+                                        kRoleNone, kRoleHash, kRoleTwins, kRoleNone, kRoleNone, kRoleBuilder, kRoleEmit, kRoleNone };
+#elif TSQ_X_MAP == 7   // SIMD 0: WALK; SIMD 1: ORBIT0, MATCH0, HASH, BUILDER; SIMD 2: ORBIT1, MATCH1, TWINS, EMIT; SIMD 3: ACCOUNT, NEAR, COMMIT
+    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNone, kRoleMatch0, kRoleMatch1, kRoleNear,
+                                        kRoleNone, kRoleHash, kRoleTwins, kRoleCommit, kRoleNone, kRoleBuilder, kRoleEmit, kRoleNone };
+#elif TSQ_X_MAP == 9   // SIMD 3: ACCOUNT, BUILDER;  EMIT -> SIMD 2
+    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleBuilder,
+                                        kRoleNone, kRoleHash, kRoleTwins, kRoleNone, kRoleNone, kRoleCommit, kRoleEmit, kRoleNone };
+#elif TSQ_X_MAP == 10  // SIMD 3: ACCOUNT, EMIT;  BUILDER -> SIMD 2
+    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleEmit,
+                                        kRoleNone, kRoleHash, kRoleTwins, kRoleNone, kRoleNone, kRoleCommit, kRoleBuilder, kRoleNone };
+#elif TSQ_X_MAP == 11  // SIMD 0: WALK, NEAR, BUILDER;  SIMD 3: ACCOUNT, EMIT
+    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleEmit,
+                                        kRoleBuilder, kRoleHash, kRoleTwins, kRoleNone, kRoleNone, kRoleCommit, kRoleNone, kRoleNone };
+#elif TSQ_X_MAP == 5   // SIMD 2: ORBIT1, MATCH1, TWINS, COMMIT (SIMD 1 keeps ORBIT0, MATCH0, HASH)
+    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleBuilder,
+                                        kRoleNone, kRoleHash, kRoleTwins, kRoleEmit, kRoleNone, kRoleNone, kRoleCommit, kRoleNone };
+#endif
     constexpr uint32_t role_map_lean[16] = { kRoleWalk, kRoleOrbit0, kRoleMatch0, kRoleHash, kRoleEmit, kRoleBuilder, kRoleAccount, kRoleOrbit1,
                                              kRoleCommit, kRoleTwins, kRoleMatch1, kRoleNear, kRoleNone, kRoleNone, kRoleNone, kRoleNone };
     uint32_t role = kRoleNone;
@@ -1337,7 +1391,7 @@ __global__ __launch_bounds__(1024) void enc_stage_kernel(const uint8_t* __restri
     else if (role == kRoleBuilder) stream_builder<StageCfg>(lds3, lane);
 #ifdef TSQ_SPINS
     if (blockIdx.x == 0 && lane == 0) g_enc_spins[threadIdx.x >> 6] = reinterpret_cast<uint32_t*>(stage_lds + StageCfg::off_ctl)[48u + (threadIdx.x >> 6)];
-    if (blockIdx.x == 0 && role == kRoleAccount && lane == 0) g_enc_spins[12] = reinterpret_cast<uint32_t*>(stage_lds + StageCfg::off_ctl)[60];   // (ACCOUNT leaves after WALK)
+    if (blockIdx.x == 0 && role == kRoleEmit && lane == 0) for (uint32_t q = 0; q < 4u; ++q) g_enc_spins[16u + q] = reinterpret_cast<uint32_t*>(stage_lds + StageCfg::off_ctl)[44u + q];   // (EMIT leaves last)
 #endif
 }
 

@@ -29,6 +29,25 @@ constexpr uint32_t kTraceFrom = 20000;
 #define TSQ_SUB(slot) TSQ_ACC(slot)
 #endif
 
+// Light instrumentation (-DTSQ_SPINS, make spins, tools/spin_counts.py): every unsuccessful poll of every wavefront is counted in
+// LDS (one ds_add per spin, nothing on the paths that do not wait), so that who waits for whom shows at production timing.
+#ifdef TSQ_SPINS
+__device__ uint32_t g_enc_spins[20];
+#define TSQ_SPIN(ctl) do { if ((threadIdx.x & 63u) == 0u) __hip_atomic_fetch_add(&(ctl)[48u + (threadIdx.x >> 6)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
+#define TSQ_SPIN_AT(ctl, slot) do { if ((threadIdx.x & 63u) == 0u) __hip_atomic_fetch_add(&(ctl)[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
+#else
+#define TSQ_SPIN(ctl) do {} while (0)
+#define TSQ_SPIN_AT(ctl, slot) do {} while (0)
+#endif
+
+// Bottleneck finder (-DTSQ_X_DELAY_STAGE=k, tools/xbuild.sh): stage k sleeps 128 cycles per tile (per item / per batch for BUILDER / EMIT); the
+// stage whose delay shows one to one in the kernel time paces the pipeline.
+#ifdef TSQ_X_DELAY_STAGE
+#define TSQ_DELAY(k) do { if ((k) == TSQ_X_DELAY_STAGE) __builtin_amdgcn_s_sleep(2); } while (0)
+#else
+#define TSQ_DELAY(k) do {} while (0)
+#endif
+
 // 16 bytes at src+at, zeros past `avail`
 __device__ __forceinline__ uint4 ld128z(const uint8_t* src, uint64_t at, uint64_t avail)
 {

@@ -611,7 +611,7 @@ extern "C" int tsqa_measure_copy(tsqa_ctx* c, size_t bytes, int reps, double* be
 #ifdef TSQ_SPINS
 extern "C" int tsqa_debug_spins(uint32_t* out16)
 {
-    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(tsq::g_enc_spins), 16 * sizeof(uint32_t)) == hipSuccess ? TSQA_OK : TSQA_ERR_HIP;
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(tsq::g_enc_spins), 20 * sizeof(uint32_t)) == hipSuccess ? TSQA_OK : TSQA_ERR_HIP;
 }
 #endif
 #ifdef TSQ_STATS
