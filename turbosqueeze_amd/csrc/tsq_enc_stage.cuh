@@ -1108,6 +1108,9 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
             slot_publish();
         }
         Vt = 0; Mt = 0;
+        // what the next item starts from: the symbol state as it stands (nothing changes it before the next segment or query, and a
+        // query that pushes a symbol of its own sets these itself)
+        e_nsym = nsym; e_origin = origin; e_lit_from = lit_from;
     };
     // exact effect of a segment on the symbol state, one step per literal RUN or match (used when a run
     // reaches a 16-byte chunk boundary inside the segment: incompressible data, runs of equal bytes)
@@ -1186,10 +1189,6 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
             __hip_atomic_store(&ctl[kCtlAccounted], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             TSQ_DELAY(7);
             TSQ_CNT(15, 1);
-        }
-        {
-            const uint32_t fresh = s_nz64(Vt) ^ 1u;
-            e_nsym = s_sel(fresh, nsym, e_nsym); e_origin = s_sel(fresh, origin, e_origin); e_lit_from = s_sel(fresh, lit_from, e_lit_from);
         }
         if (kind == kEvSeg) {
             // ---- the segment's effect on the symbol state, O(1) from its masks.  `dsym` symbols close (matches and
@@ -1309,47 +1308,13 @@ __global__ __launch_bounds__(1024) void enc_stage_kernel(const uint8_t* __restri
     const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u;
     // Wave w of a workgroup runs on SIMD w % 4 (read back from HW_ID in the instrumented build).  WALK, the serial stage, gets a SIMD
     // almost to itself (NEAR, a light stage, shares it): the two other wavefronts of SIMD 0 leave right after the prologue.
-    //   SIMD 0: WALK, NEAR      SIMD 1: ORBIT even, MATCH even, HASH, COMMIT     SIMD 2: ORBIT odd, MATCH odd, TWINS     SIMD 3: ACCOUNT, BUILDER, EMIT
-    // (measured and dropped: s_setprio on the lag loop's stages or on WALK, COMMIT / EMIT / HASH on SIMD 0, NEAR on SIMD 2 or 3: all within 0.3 %)
+    //   SIMD 0: WALK, NEAR      SIMD 1: ORBIT even, MATCH even, HASH, BUILDER     SIMD 2: ORBIT odd, MATCH odd, TWINS, EMIT     SIMD 3: ACCOUNT, COMMIT
+    // (measured: ACCOUNT next to WALK on SIMD 0 costs 8 to 13 ms -- WALK polls without sleeping and starves the wavefront whose
+    //  answers it waits for; a third ORBIT wavefront +1.4 ms; s_setprio, COMMIT / EMIT / HASH on SIMD 0, NEAR on SIMD 2 or 3: within 0.3 %)
     enum : uint32_t { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNone, kRoleMatch0, kRoleMatch1, kRoleBuilder, kRoleHash, kRoleTwins, kRoleEmit, kRoleCommit, kRoleNear };
     // (the lean layout -- two workgroups per CU -- launches the twelve working wavefronts only: 2 x 16 do not fit a CU's wave slots)
-#ifndef TSQ_X_MAP
-#define TSQ_X_MAP 6
-#endif
-#if TSQ_X_MAP == 0
-    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleBuilder,
-                                        kRoleNone, kRoleHash, kRoleTwins, kRoleEmit, kRoleNone, kRoleCommit, kRoleNone, kRoleNone };
-#elif TSQ_X_MAP == 1   // SIMD 0: WALK, ACCOUNT;  SIMD 3: NEAR, BUILDER, EMIT
-    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleNear, kRoleAccount, kRoleMatch0, kRoleMatch1, kRoleBuilder,
-                                        kRoleNone, kRoleHash, kRoleTwins, kRoleEmit, kRoleNone, kRoleCommit, kRoleNone, kRoleNone };
-#elif TSQ_X_MAP == 2   // SIMD 0: WALK, NEAR, ACCOUNT;  SIMD 3: BUILDER, EMIT
-    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleNone, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleBuilder,
-                                        kRoleAccount, kRoleHash, kRoleTwins, kRoleEmit, kRoleNone, kRoleCommit, kRoleNone, kRoleNone };
-#elif TSQ_X_MAP == 3   // SIMD 0: WALK, NEAR;  SIMD 1: ORBIT0, MATCH0, HASH;  SIMD 2: ORBIT1, MATCH1, TWINS;  SIMD 3: ACCOUNT, BUILDER, EMIT, COMMIT
-    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleBuilder,
-                                        kRoleNone, kRoleHash, kRoleTwins, kRoleEmit, kRoleNone, kRoleNone, kRoleNone, kRoleCommit };
-#elif TSQ_X_MAP == 4   // SIMD 0: WALK, NEAR, COMMIT;  SIMD 1: ORBIT0, MATCH0, HASH
-    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleBuilder,
-                                        kRoleCommit, kRoleHash, kRoleTwins, kRoleEmit, kRoleNone, kRoleNone, kRoleNone, kRoleNone };
-#elif TSQ_X_MAP == 6   // SIMD 0: WALK, NEAR; SIMD 1: ORBIT0, MATCH0, HASH, BUILDER; SIMD 2: ORBIT1, MATCH1, TWINS, EMIT; SIMD 3: ACCOUNT, COMMIT
     constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleCommit,
                                         kRoleNone, kRoleHash, kRoleTwins, kRoleNone, kRoleNone, kRoleBuilder, kRoleEmit, kRoleNone };
-#elif TSQ_X_MAP == 7   // SIMD 0: WALK; SIMD 1: ORBIT0, MATCH0, HASH, BUILDER; SIMD 2: ORBIT1, MATCH1, TWINS, EMIT; SIMD 3: ACCOUNT, NEAR, COMMIT
-    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNone, kRoleMatch0, kRoleMatch1, kRoleNear,
-                                        kRoleNone, kRoleHash, kRoleTwins, kRoleCommit, kRoleNone, kRoleBuilder, kRoleEmit, kRoleNone };
-#elif TSQ_X_MAP == 9   // SIMD 3: ACCOUNT, BUILDER;  EMIT -> SIMD 2
-    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleBuilder,
-                                        kRoleNone, kRoleHash, kRoleTwins, kRoleNone, kRoleNone, kRoleCommit, kRoleEmit, kRoleNone };
-#elif TSQ_X_MAP == 10  // SIMD 3: ACCOUNT, EMIT;  BUILDER -> SIMD 2
-    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleEmit,
-                                        kRoleNone, kRoleHash, kRoleTwins, kRoleNone, kRoleNone, kRoleCommit, kRoleBuilder, kRoleNone };
-#elif TSQ_X_MAP == 11  // SIMD 0: WALK, NEAR, BUILDER;  SIMD 3: ACCOUNT, EMIT
-    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleEmit,
-                                        kRoleBuilder, kRoleHash, kRoleTwins, kRoleNone, kRoleNone, kRoleCommit, kRoleNone, kRoleNone };
-#elif TSQ_X_MAP == 5   // SIMD 2: ORBIT1, MATCH1, TWINS, COMMIT (SIMD 1 keeps ORBIT0, MATCH0, HASH)
-    constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleBuilder,
-                                        kRoleNone, kRoleHash, kRoleTwins, kRoleEmit, kRoleNone, kRoleNone, kRoleCommit, kRoleNone };
-#endif
     constexpr uint32_t role_map_lean[16] = { kRoleWalk, kRoleOrbit0, kRoleMatch0, kRoleHash, kRoleEmit, kRoleBuilder, kRoleAccount, kRoleOrbit1,
                                              kRoleCommit, kRoleTwins, kRoleMatch1, kRoleNear, kRoleNone, kRoleNone, kRoleNone, kRoleNone };
     uint32_t role = kRoleNone;
