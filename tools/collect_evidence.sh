@@ -37,4 +37,6 @@ for args in "--synthetic 1000000000 --reps 5 --no-ext" "--synthetic 1000000000 -
 tools/micro/lds_unaligned > $OUT/lds_access_costs.txt 2>&1
 TSQ_BENCH_BACKEND=gloo TSQ_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --steps 5 --warmup 2 --no-weak 2>/dev/null | tail -1 > $OUT/bench_2ranks_1gpu.json
 (TSQ_AMD_DEBUG=1 timeout 200 tools/tsq_cli b --synthetic 1000000000 --reps 2 --no-ext 2>&1 | tail -45) > $OUT/cli_timeline.txt
+mkdir -p gpurun_out/x; bash tools/bottleneck.sh run > $OUT/bottleneck.txt 2>&1
+python tools/spin_counts.py > $OUT/spin_counts.txt 2>&1
 ls -la $OUT
