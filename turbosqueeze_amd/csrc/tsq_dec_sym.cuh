@@ -34,6 +34,10 @@
 #include "tsq_common.cuh"
 #include "tsq_dec_common.cuh"
 
+#ifndef TSQ_X_PL
+#define TSQ_X_PL 0
+#endif
+
 namespace tsq {
 
 struct SymCfg {
@@ -209,6 +213,45 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
         // pass.  An offset at or beyond slim is terminal (TERM).
         {
             uint32_t x[C::PER], y[C::PER], c[C::PER];
+#if TSQ_X_PL
+            // (A) every byte of the chunk taken as a size byte: the stream length of the pair it would head, for each of the four
+            //     control-bit pairs, packed in one word: 5 | 4 + lo << 8 | 4 + hi << 16 | 3 + hi + lo << 24 (tsq_decode.cpp:66-88: a
+            //     literal takes nibble + 1 bytes, a match two).  One lane per aligned word of the chunk, arithmetic only.  The table
+            //     lies over the doubling tables (dead until P2).
+            {
+                uint32_t* const pl = reinterpret_cast<uint32_t*>(lds + SymLds::j4);
+                constexpr uint32_t NW = (C::S + C::SPAD) / 4u;
+#pragma unroll
+                for (uint32_t k = 0; k < (NW + C::T - 1u) / C::T; ++k) {
+                    const uint32_t w = tid + k * C::T;
+                    if (w < NW) {
+                        const uint32_t v = reinterpret_cast<const uint32_t*>(sbuf)[w];
+                        uint32_t q[4];
+#pragma unroll
+                        for (uint32_t b = 0; b < 4; ++b) {
+                            const uint32_t hi = (v >> (8u * b + 4u)) & 15u, lo = (v >> (8u * b)) & 15u;
+                            const uint32_t a = lo | (lo << 16), h2 = hi | (hi << 8);
+                            q[b] = (a << 8) + 0x03040405u + (h2 << 16);
+                        }
+                        *reinterpret_cast<uint4*>(pl + 4u * w) = make_uint4(q[0], q[1], q[2], q[3]);
+                    }
+                }
+            }
+            __syncthreads();
+            // (B) the four pairs of the group that would start at each offset: one table word per pair
+            {
+                const uint32_t* const pl = reinterpret_cast<const uint32_t*>(lds + SymLds::j4);
+#pragma unroll
+                for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t o = tid + k * C::T; c[k] = (uint32_t)sbuf[o] << 3; x[k] = o + 1u; }
+#pragma unroll
+                for (uint32_t pr = 0; pr < 4; ++pr) {
+#pragma unroll
+                    for (uint32_t k = 0; k < C::PER; ++k) y[k] = pl[x[k]];                     // x < S + 133: inside the padded buffer
+#pragma unroll
+                    for (uint32_t k = 0; k < C::PER; ++k) x[k] += __builtin_amdgcn_ubfe(y[k], (c[k] >> (6u - 2u * pr)) & 0x18u, 8u);
+                }
+            }
+#else
 #pragma unroll
             for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t o = tid + k * C::T; c[k] = sbuf[o]; x[k] = o + 1u; }
 #pragma unroll
@@ -222,6 +265,7 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
 #pragma unroll
                 for (uint32_t k = 0; k < C::PER; ++k) x[k] += y[k];
             }
+#endif
 #pragma unroll
             for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t o = tid + k * C::T; j1[o] = (uint8_t)(x[k] - o); x[k] = o < slim ? x[k] : C::TERM; }
             __syncthreads();
