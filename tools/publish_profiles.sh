@@ -20,6 +20,6 @@ cp $S/traffic_experiment_pmc.json profiles/${TAG}_traffic_experiment_pmc.json
 cp $S/quick_check.txt profiles/${TAG}_quick_check.txt
 cp $S/bottleneck.txt profiles/${TAG}_encoder_bottleneck.txt
 cp $S/spin_counts.txt profiles/${TAG}_encoder_spin_counts.txt
-[ -f $S/sq_counters.txt ] && cp $S/sq_counters.txt profiles/${TAG}_sq_counters.txt
+[ -f gpurun_out/${TAG}_sq.log ] && grep -v amdgpu.ids gpurun_out/${TAG}_sq.log > profiles/${TAG}_sq_counters.txt
 [ -f $S/regions.txt ] && cp $S/regions.txt profiles/${TAG}_walk_regions.txt
 ls -la profiles/${TAG}_*

@@ -5,8 +5,9 @@
 // workgroup of 16 wavefronts:
 //
 //   P0  stage the chunk (prefetched into registers while the previous chunk was being copied).
-//   P1  every byte offset is parsed AS IF a group (control byte + 4 pairs) started there: four chained lookups in a
-//       1024-entry table indexed by (two control bits, size byte) that gives a pair's stream length and output length.
+//   P1  every byte offset is parsed AS IF a group (control byte + 4 pairs) started there: first every byte is taken as a size byte
+//       (the stream length of the pair it would head under each of the four control-bit pairs, packed in one word: arithmetic
+//       only), then four chained look-ups of those words, one per pair.
 //   P2  pointer doubling: next^2, next^4, next^8, next^16 (all kept).
 //   P3  one lane follows next^16 from the known chunk start (one dependent LDS hop per 16 groups), with the LDS to itself.
 //   P4  one lane per group: its start from the hop it hangs on and the bits of its index (next^8, ^4, ^2, ^1: four
@@ -33,10 +34,6 @@
 
 #include "tsq_common.cuh"
 #include "tsq_dec_common.cuh"
-
-#ifndef TSQ_X_PL
-#define TSQ_X_PL 0
-#endif
 
 namespace tsq {
 
@@ -148,8 +145,6 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
 #endif
     TSQD_T0();
     if (tid == 0) { misc[4] = 0; misc[9] = 0; misc[10] = 0; }
-    uint16_t* const lut = reinterpret_cast<uint16_t*>(lds + SymLds::lut);
-    { uint32_t sl, ol; pair_lens(tid & 255u, tid >> 8, 0u, sl, ol); lut[tid] = (uint16_t)sl; }
     uint32_t sp = 3, op = 0;
     uint32_t ring_op = oskew;            // ring address of position op
     // what P7 still has to write out: the previous chunk's image
@@ -213,7 +208,6 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
         // pass.  An offset at or beyond slim is terminal (TERM).
         {
             uint32_t x[C::PER], y[C::PER], c[C::PER];
-#if TSQ_X_PL
             // (A) every byte of the chunk taken as a size byte: the stream length of the pair it would head, for each of the four
             //     control-bit pairs, packed in one word: 5 | 4 + lo << 8 | 4 + hi << 16 | 3 + hi + lo << 24 (tsq_decode.cpp:66-88: a
             //     literal takes nibble + 1 bytes, a match two).  One lane per aligned word of the chunk, arithmetic only.  The table
@@ -251,21 +245,6 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
                     for (uint32_t k = 0; k < C::PER; ++k) x[k] += __builtin_amdgcn_ubfe(y[k], (c[k] >> (6u - 2u * pr)) & 0x18u, 8u);
                 }
             }
-#else
-#pragma unroll
-            for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t o = tid + k * C::T; c[k] = sbuf[o]; x[k] = o + 1u; }
-#pragma unroll
-            for (uint32_t pr = 0; pr < 4; ++pr) {
-#pragma unroll
-                for (uint32_t k = 0; k < C::PER; ++k) y[k] = sbuf[x[k]];                        // x < S + 133: inside the padded buffer
-                // the pair's stream length from a 2 KB table in LDS indexed by (two control bits, size byte): one more LDS read per step, but
-                // eight VALU instructions fewer (4.6 K cycles per chunk against 5.4 K by arithmetic)
-#pragma unroll
-                for (uint32_t k = 0; k < C::PER; ++k) y[k] = lut[(((c[k] >> (6u - 2u * pr)) & 3u) << 8) | y[k]];
-#pragma unroll
-                for (uint32_t k = 0; k < C::PER; ++k) x[k] += y[k];
-            }
-#endif
 #pragma unroll
             for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t o = tid + k * C::T; j1[o] = (uint8_t)(x[k] - o); x[k] = o < slim ? x[k] : C::TERM; }
             __syncthreads();
