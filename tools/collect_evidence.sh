@@ -7,8 +7,10 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 (lscpu | head -25; echo "cgroup cpu.max: $(cat /sys/fs/cgroup/cpu.max 2>/dev/null)"; nproc; free -g | head -2; rocm-smi --showproductname 2>/dev/null | head -12) > $OUT/gpu_box_host.txt 2>&1
 (timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5) > $OUT/pytest_gpu.log
-(timeout 600 python bench.py --steps 10 --warmup 3 2>&1 | tail -1) > $OUT/bench.json
 bash tools/profile_round.sh $TAG > $OUT/profile_round.log 2>&1
+# (bench.py takes roofline.traffic from the newest PMC summary under profiles/ that carries the running kernels' fingerprint: the one just made)
+cp $OUT/pmc_summary.json profiles/${TAG}_pmc_fetch_write.json
+(timeout 600 python bench.py --steps 10 --warmup 3 2>&1 | tail -1) > $OUT/bench.json
 python tools/phase_stats.py > $OUT/phase_stats.txt 2>&1
 python tools/traffic_experiment.py > $OUT/traffic_experiment.jsonl 2>/dev/null
 (cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
