@@ -6,6 +6,10 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import turbosqueeze_amd as tsq
+from turbosqueeze_amd import api
+if os.environ.get("TSQ_LIB"):
+    api.lib_path = lambda ab=False: os.path.join(ROOT, "turbosqueeze_amd", os.environ["TSQ_LIB"])
+    api._libs.clear()
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 30
 ext = int(sys.argv[2]) if len(sys.argv) > 2 else 1

@@ -1315,8 +1315,9 @@ __global__ __launch_bounds__(1024) void enc_stage_kernel(const uint8_t* __restri
     // (the lean layout -- two workgroups per CU -- launches the twelve working wavefronts only: 2 x 16 do not fit a CU's wave slots)
     constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleCommit,
                                         kRoleNone, kRoleHash, kRoleTwins, kRoleNone, kRoleNone, kRoleBuilder, kRoleEmit, kRoleNone };
-    constexpr uint32_t role_map_lean[16] = { kRoleWalk, kRoleOrbit0, kRoleMatch0, kRoleHash, kRoleEmit, kRoleBuilder, kRoleAccount, kRoleOrbit1,
-                                             kRoleCommit, kRoleTwins, kRoleMatch1, kRoleNear, kRoleNone, kRoleNone, kRoleNone, kRoleNone };
+    // (lean layout, measured at 4 GiB: this placement 30.7 GB/s on text against 29.4 for the round's earlier one)
+    constexpr uint32_t role_map_lean[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleBuilder,
+                                             kRoleCommit, kRoleHash, kRoleTwins, kRoleEmit, kRoleNone, kRoleNone, kRoleNone, kRoleNone };
     uint32_t role = kRoleNone;
 #pragma unroll
     for (uint32_t w = 0; w < 16u; ++w) role = (threadIdx.x >> 6) == w ? (WINDOW ? role_map[w] : role_map_lean[w]) : role;
