@@ -741,14 +741,16 @@ __device__ __forceinline__ uint32_t s_lsb64(uint64_t x)                   // x !
 //   WALK     decides which positions the parse VISITS -- the only thing MATCH (the position table) and the next tile need.  Per tile:
 //            the orbit of the actual entry lane (three v_readlane), the check for visited twins, and for a hazard lane its candidate
 //            (the most recent visited twin, or the gathered one) and common prefix.  A hazard whose candidate lies far enough back
-//            that the pair origin cannot matter is decided on the spot; the others (candidate closer than kDMin, block tail) are
-//            QUERIES: ACCOUNT, which holds the symbol state, answers with the next position.
+//            that the pair origin cannot matter is decided on the spot and its class patched into the tile record; the others
+//            (candidate right behind the last match, block tail) are QUERIES: ACCOUNT, which holds the symbol state, answers with
+//            the next position.
 //   ACCOUNT  the symbol accounting of tsq_encode.cpp:93-95,113-115,157-159 -- symbol count, pair origin, pending literal, the
-//            reference-time origin inside literal runs -- in O(1) per segment from its masks, the exact scalar decision of every
-//            hazard lane (tsq_encode.cpp:100,139-145), and the items for the BUILDER.  It trails WALK by an event or two.
+//            reference-time origin inside literal runs -- in O(1) per segment from its masks and the tile record, the exact scalar
+//            decision of the queries (tsq_encode.cpp:100,139-145), and the items for the BUILDER.  It trails WALK by an event or two.
 //
-// Events (8 words each, a single-producer/single-consumer ring in LDS): kEvSeg {base, V lo, V hi}: the lanes of tile `base` visited
-// by one hazard-free stretch of the orbit; kEvHaz {i, candidate, k | twin << 8 | local << 9}: one hazard lane; kEvEnd.
+// Events (4 words each, a single-producer/single-consumer ring in LDS): kEvSeg {base, V lo, V hi}: lanes of tile `base` the parse
+// visited (everything since the tile's previous event; the classes of the hazard lanes among them that WALK decided are in the
+// record by the time the event is pushed); kEvHaz {i, candidate, k | twin << 8}: a query; kEvEnd.
 
 template <bool EXT, bool WINDOW>
 __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, uint32_t n, lds_u8_t* lds, uint32_t lane)
