@@ -19,7 +19,7 @@ else
 import re
 rows = {}
 for line in open("gpurun_out/x/bottleneck_raw.txt"):
-    m = re.match(r"== (s\w+):.*PARITY (\w+).*encode kernel ([\d.]+) ms", line)
+    m = re.match(r"== (s\w+):.*PARITY (\w+).*ext=\d: encode kernel ([\d.]+) ms", line)
     if m: rows[m.group(1)] = (float(m.group(3)), m.group(2))
 base = rows["s_none"][0]
 tiles = 65537
