@@ -138,8 +138,9 @@ def init_distributed(backend: str):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("TSQ_BENCH_FORCE_SHARDED"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend, rank=rank, world_size=world)
     return world, rank, local_rank
@@ -152,7 +153,7 @@ def timed_steps(step, steps: int, warmup: int, world: int, device_sync, reduce_d
     import torch.distributed as dist
 
     def barrier():
-        if world > 1:
+        if dist.is_available() and dist.is_initialized():
             dist.barrier()
         device_sync()
 
@@ -164,7 +165,7 @@ def timed_steps(step, steps: int, warmup: int, world: int, device_sync, reduce_d
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         tt = torch.tensor([dt], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -207,6 +208,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-oracle-check", action="store_true", help="N = 1: skip the comparison of the timed job's container with the CPU oracle (after the timed region)")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the extra weak-scaling measurement")
+    ap.add_argument("--no-throughput", action="store_true", help="N = 1: skip the extra chip-filling measurement (4 GiB of the same text = 1 024 blocks)")
+    ap.add_argument("--throughput-size", type=int, default=4 << 30)
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = production, 1 = serial baselines, 5 = round 2's encoder from the A/B library)")
     args = ap.parse_args()
 
@@ -217,7 +220,10 @@ def main():
     import turbosqueeze_amd as tsq
     from turbosqueeze_amd import sharding
 
-    # (TSQ_BENCH_BACKEND=gloo TSQ_BENCH_SHARE_GPU=1: dry run of the N > 1 path with every rank on GPU 0 -- for a 1-GPU box)
+    # (TSQ_BENCH_BACKEND=gloo TSQ_BENCH_SHARE_GPU=1: dry run of the N > 1 path with every rank on GPU 0 -- for a 1-GPU box;
+    #  TSQ_BENCH_FORCE_SHARDED=1: the N > 1 path with a world of ONE rank -- process group, RCCL all-gather, host container,
+    #  hipHostRegister, both sharded C calls -- which is how tests/test_gpu_parity.py executes the RCCL branch on a 1-GPU box)
+    force_sharded = bool(os.environ.get("TSQ_BENCH_FORCE_SHARDED"))
     backend = os.environ.get("TSQ_BENCH_BACKEND", "nccl")
     world, rank, local_rank = init_distributed(backend)
     if os.environ.get("TSQ_BENCH_SHARE_GPU"):
@@ -231,7 +237,7 @@ def main():
     codec = tsq.DeviceCodec(local_rank, ab=args.variant == 5)
     codec.set_variant(args.variant, args.variant if args.variant in (0, 1) else 0)
 
-    def single_gpu_job(seed, steps, warmup, check_oracle=False):
+    def single_gpu_job(seed, steps, warmup, check_oracle=False, n=n, nb=nb):
         """The N=1 step on this rank's own job.  -> (dt, comp_bytes, enc/dec kernel ms+launches, call ms, container == oracle's)"""
         host = tsq.synth.text(n, seed=seed)
         src = torch.from_numpy(host).to(dev)
@@ -274,10 +280,10 @@ def main():
         return dt, comp_bytes, kern, calls, oracle_equal
 
     line = None
-    if world == 1:
+    if world == 1 and not force_sharded:
         dt, comp_bytes, (enc_ms, enc_n, dec_ms, dec_n), (cmp_ms, cmp_n, dcm_ms, dcm_n), oracle_equal = single_gpu_job(1, args.steps, args.warmup, check_oracle=not args.no_oracle_check)
         peak_best, peak_med = codec.measure_copy(4 << 30, 7)
-        probe_shape = codec.last_error()
+        probe_shape = codec.copy_probe_shape()
         alg, enc_e, dec_e, dom, enc_avg, dec_avg = roofline_entries(n, comp_bytes, enc_ms, enc_n, dec_ms, dec_n, peak_best)
         traffic, traffic_src = (None, "PMC summaries are collected for the default job only")
         fingerprint = tsq.source_fingerprint()
@@ -310,6 +316,26 @@ def main():
             "encode_kernel_GBps": round(n / enc_avg / 1e9, 4) if enc_avg > 0 else 0.0,
             "decode_kernel_GBps": round(n / dec_avg / 1e9, 4) if dec_avg > 0 else 0.0,
         }
+        if not args.no_throughput:
+            # The headline job has fewer blocks (239) than the GPU has CUs (256): with one workgroup per block its kernel times are
+            # per-block latencies.  The chip-filling figure beside it (device-resident kernel throughput): 4 GiB of the
+            # same text = 1 024 blocks, same level, same HIP events, the timed container compared with the oracle's afterwards.
+            tn = args.throughput_size
+            tnb = (tn + tsq.BLOCK_SZ - 1) // tsq.BLOCK_SZ
+            tsteps = 3
+            tdt, tcomp, (te_ms, te_n, td_ms, td_n), _, t_equal = single_gpu_job(1, tsteps, 1, check_oracle=not args.no_oracle_check, n=tn, nb=tnb)
+            t_alg, te_e, td_e, _, te_avg, td_avg = roofline_entries(tn, tcomp, te_ms, te_n, td_ms, td_n, peak_best)
+            line["throughput"] = {
+                "workload": f"{tn} B of the same enwik9-shaped text ({tnb} blocks of 4 MiB: more blocks than CUs), "
+                            f"{'with-extensions' if args.ext else '--no-ext'} level, device-resident, bit-exact round trip",
+                "job_bytes": tn, "blocks": tnb, "steps": tsteps, "ratio": round(tcomp / tn, 5), "container_equals_oracle": t_equal,
+                "value": round(aggregate_value(tn, tdt, tsteps), 4), "unit": "GB/s",
+                "encode_kernel_GBps": round(tn / te_avg / 1e9, 3) if te_avg > 0 else 0.0,
+                "decode_kernel_GBps": round(tn / td_avg / 1e9, 3) if td_avg > 0 else 0.0,
+                "encode_kernel_ms": round(te_avg * 1e3, 3), "decode_kernel_ms": round(td_avg * 1e3, 3),
+                "algorithmic_bytes_per_launch": t_alg,
+                "roofline_encode": te_e, "roofline_decode": td_e,     # (N + C) / t against 8 TB/s and against the measured copy
+            }
         if not args.no_cpu_baseline:
             # bounded sample, but never fewer blocks than 2 per host thread (block-parallel CPU code)
             line["cpu_baseline"] = cpu_baseline(min(n, args.cpu_sample), args.ext)
@@ -328,6 +354,7 @@ def main():
             hc = sharding.HostContainer(name, cap, create=False)
         hc.register()
         sc = sharding.ShardedCodec(lay, sharding.DeviceBlocks(codec, collective_device=red_dev), hc, args.ext)
+        sc.always_gather = force_sharded                  # (a world of one still runs the all-gather)
         d_back = torch.empty(max(lay.shard_bytes, 1), dtype=torch.uint8, device=dev)
         size_seen = [0]
 
@@ -361,9 +388,16 @@ def main():
         assert torch.equal(d_back[:lay.shard_bytes], expect), "round trip mismatch on rank %d" % rank
         comp_bytes = size_seen[0]
         # the host-gathered container is a well-formed .tsq file of the whole job
+        oracle_equal = None
         if rank == 0:
             total, frame_at, sizes, ext_bits, out_len = sharding.walk_frames(hc.array, comp_bytes)
             assert total == n and len(sizes) == nb and int(frame_at[-1]) + 3 + int(sizes[-1]) == comp_bytes
+            if not args.no_oracle_check:
+                # ... and, outside the timed region, byte for byte the CPU oracle's container of the same job (the checker)
+                from oracle import pyoracle
+                want = pyoracle.Oracle().compress(tsq.synth.text(n, seed=1), args.ext, threads=min(32, os.cpu_count() or 1))
+                oracle_equal = bool(len(want) == comp_bytes and bytes(hc.array[:comp_bytes]) == want)
+                assert oracle_equal, "the host-gathered container differs from the oracle's"
         # the slowest rank's kernel times
         kt = torch.tensor([enc_ms / max(enc_n, 1), dec_ms / max(dec_n, 1)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(kt, op=dist.ReduceOp.MAX)
@@ -387,7 +421,7 @@ def main():
                                        f"{'with-extensions' if args.ext else '--no-ext'} level, blocks resident in HBM, container gathered in host memory, bit-exact round trip",
                            "job_bytes": n, "blocks": nb, "ext": args.ext, "ratio": round(comp_bytes / n, 5),
                            "sharding": f"block b -> rank b % {world}; one all-gather of the u32 sizes per step, frames DMA'd to one host container, barrier, owned frames back and decoded",
-                           "kernel_variant": args.variant},
+                           "kernel_variant": args.variant, "container_equals_oracle": oracle_equal, "collective_backend": backend},
                 "slowest_rank_kernel_ms": {"encode": round(enc_avg * 1e3, 4), "decode": round(dec_avg * 1e3, 4)},
                 "rank0_step_breakdown_ms": breakdown,
                 "note": "one workgroup per 4 MiB block: the kernel time of a 239-block job is the per-block latency at any N (DESIGN.md section 6)",
@@ -396,7 +430,7 @@ def main():
                 line["weak_scaling"] = weak
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -177,7 +177,9 @@ int tsqa_profile_read_calls(tsqa_ctx *ctx, double *compress_ms, uint32_t *compre
  *   d_slots + (b / world) * TSQ_OUTPUT_SZ) goes by DMA to its final place in ONE container in host memory, with its three
  *   frame bytes; rank 0 also writes the 16-byte header.  *container_size is the same on every rank.
  * tsqa_sharded_fetch_decode_async: walks the container, brings this rank's frames back to d_streams (k-th owned frame at
- *   k * TSQ_OUTPUT_SZ) and decodes them back to back into d_out (k-th owned block at k * TSQ_BLOCK_SZ).
+ *   k * TSQ_OUTPUT_SZ) and decodes them back to back into d_out (k-th owned block at k * TSQ_BLOCK_SZ).  The container is not
+ *   trusted: its whole frame walk is validated against container_size and against streams_cap / out_cap (the bytes the two device
+ *   buffers hold) before any copy is enqueued; TSQA_ERR_FORMAT otherwise, with nothing written.
  * Both replace the Python loops of round 2's sharding.py; the host container should be pinned / hipHostRegister'ed. */
 int tsqa_frame_offsets(const uint32_t *sizes, uint32_t n_blocks, uint64_t *frame_at, uint64_t *container_size);
 int tsqa_walk_frames(const void *container, size_t size, uint32_t cap_blocks, uint64_t *frame_at, uint32_t *sizes, uint32_t *ext,
@@ -186,20 +188,23 @@ int tsqa_sharded_place_async(tsqa_ctx *ctx, const void *d_slots, const uint32_t 
                              uint32_t rank, uint32_t world, uint32_t ext, void *host_container, size_t host_cap,
                              uint64_t *container_size, void *hip_stream);
 int tsqa_sharded_fetch_decode_async(tsqa_ctx *ctx, const void *host_container, size_t container_size, uint32_t rank, uint32_t world,
-                                    void *d_streams, void *d_out, int32_t *d_status, uint64_t *total, void *hip_stream);
+                                    void *d_streams, size_t streams_cap, void *d_out, size_t out_cap, int32_t *d_status, uint64_t *total,
+                                    void *hip_stream);
 
 /* The measured copy bandwidth of this GPU (bytes read + bytes written per second, GB/s = 1e9 B/s) by a plain
  * grid-stride 16-byte copy kernel over `bytes` of HBM: the second denominator beside the 8 TB/s specification when a
  * kernel is priced against the HBM roofline. */
 int tsqa_measure_copy(tsqa_ctx *ctx, size_t bytes, int reps, double *best_gbps, double *median_gbps);
+/* which launch shape the last tsqa_measure_copy on this context chose (text; "" before the first probe) */
+const char *tsqa_copy_probe_shape(const tsqa_ctx *ctx);
 
-/* Kernel variant selection.  Encoder: 0 = default (eleven-wave staged encoder; its lean layout by itself when there are
+/* Kernel variant selection.  Encoder: 0 = default (twelve-wave staged encoder; its lean layout by itself when there are
  * more blocks than CUs), 1 = serial kernel (one lane walks the block; correctness baseline), 6 = force the lean layout
  * (two blocks per CU), 7 = never lean.  Decoder: 0 = default (byte-lane decoder; on two workgroups per block when a
  * launch has at most half as many blocks as the device has CUs, three -- two of them parsing alternate windows of the stream --
  * when it has at most a third), 1 = serial kernel, 3 = several workgroups per block whatever the block count (three when the
- * CUs allow), 4 = always one, 5 = always three, 6 = always two.  Superseded kernel generations (encoder 5 = round 2's five-wave encoder; decoder 8, 9 = round 1's
- * byte-granular ring decoder) exist only in the A/B library built by `make ab`; the product library rejects them. */
+ * CUs allow), 4 = always one, 5 = always three, 6 = always two.  The previous round's production encoder (encoder 5) exists only in the A/B library
+ * built by `make ab`; the product library rejects it. */
 void tsqa_set_kernel_variant(tsqa_ctx *ctx, int encode_variant, int decode_variant);
 
 /* =====================================================================================

@@ -339,7 +339,7 @@ def test_all_kernel_variants_agree(tsq, oracle):
     host = np.concatenate([tsq.synth.text(6_000_000, seed=21), tsq.synth.mix(3_000_000, seed=22)])
     dev = to_dev(host)
     want = {ext: oracle.compress(host, ext, threads=4) for ext in (0, 1)}
-    for ab, variants in ((False, ((0, 0), (1, 1), (6, 3), (7, 4), (0, 5), (0, 6))), (True, ((0, 0), (5, 8), (5, 9)))):
+    for ab, variants in ((False, ((0, 0), (1, 1), (6, 3), (7, 4), (0, 5), (0, 6))), (True, ((0, 0), (5, 0)))):
         assert os.path.exists(tsq.lib_path(ab)), "run __graft_entry__.build() first"
         c = tsq.DeviceCodec(0, ab=ab)
         for ext in (0, 1):
@@ -351,7 +351,7 @@ def test_all_kernel_variants_agree(tsq, oracle):
         c.close()
     # the product library does not carry the superseded kernels
     c = tsq.DeviceCodec(0)
-    c.set_variant(5, 8)
+    c.set_variant(5, 0)
     with pytest.raises(tsq.TsqError):
         c.compress(dev, 0)
     c.close()
@@ -421,3 +421,115 @@ def test_sharded_blocks_api(tsq, oracle):
                 c.close()
         finally:
             hc.close()
+
+
+@pytest.mark.parametrize("n_blocks,ext", [(40, 1), (100, 0), (128, 1), (200, 0)])
+def test_default_decoder_at_every_workgroup_split(tsq, oracle, codec, n_blocks, ext):
+    """The decode kernel the library picks BY ITSELF changes with the block count of a launch (tsq_launch.cuh: several workgroups per
+    block when the launch leaves CUs free).  One container per range -- 40, 100, 128 and 200 blocks -- compressed and decompressed
+    with the default variant; the container must be the oracle's and the round trip exact.  (the two-workgroup
+    range was reached only by forcing the variant on a 3-block input.)"""
+    n = n_blocks * (1 << 22) - 12345
+    host = tsq.synth.text(n, seed=70 + n_blocks) if n_blocks != 128 else tsq.synth.mix(n, seed=71)
+    dev = to_dev(host)
+    codec.set_variant(0, 0)
+    blob = codec.compress(dev, ext)
+    want = oracle.compress(host, ext, threads=8)
+    assert to_bytes(blob) == want
+    import torch
+    back = codec.decompress(to_dev(np.frombuffer(want, dtype=np.uint8)))
+    assert torch.equal(back, dev)
+
+
+def test_sharded_fetch_decode_refuses_a_container_of_another_job(tsq, oracle):
+    """tsqa_sharded_fetch_decode_async takes its block count from the container, which is not trusted: a container with more
+    (shorter) blocks than the device buffers were sized for, or one longer than the host mapping, is refused with TSQA_ERR_FORMAT
+    before any copy is enqueued."""
+    import torch
+    from turbosqueeze_amd import sharding
+    B = 1 << 22
+    small = tsq.synth.text(2 * B, seed=5)                                   # the job the buffers are sized for: two blocks
+    other = np.concatenate([tsq.synth.text(100_000, seed=6 + k) for k in range(5)])
+    # five short blocks in one container (the format allows any block size <= 4 MiB): built from the oracle's block streams
+    streams = [oracle.encode_block(bytes(other[k * 100_000:(k + 1) * 100_000]), 0) for k in range(5)]
+    blob = b"TSQ1" + (5).to_bytes(4, "little") + (500_000).to_bytes(8, "little") + b"".join(len(s).to_bytes(3, "little") + s for s in streams)
+    hc = sharding.HostContainer("tsq_test_foreign_%d" % os.getpid(), tsq.container_bound(2 * B), create=True)
+    hc.register()
+    c = tsq.DeviceCodec(0)
+    try:
+        hc.array[:len(blob)] = np.frombuffer(blob, dtype=np.uint8)
+        lay = sharding.ShardLayout(2 * B, 0, 1)
+        d_streams = torch.zeros(lay.n_local * tsq.OUTPUT_SZ, dtype=torch.uint8, device="cuda")
+        d_out = torch.zeros(lay.shard_bytes, dtype=torch.uint8, device="cuda")
+        with pytest.raises(tsq.TsqError) as e:
+            c.sharded_fetch_decode_async(hc.ptr, len(blob), 0, 1, d_streams, d_out)
+        assert e.value.code == 4, e.value                                    # TSQA_ERR_FORMAT
+        torch.cuda.synchronize()
+        assert int(d_streams.max()) == 0 and int(d_out.max()) == 0          # nothing was written
+        # the same container with buffers that hold five blocks decodes
+        d_streams = torch.zeros(5 * tsq.OUTPUT_SZ, dtype=torch.uint8, device="cuda")
+        d_out = torch.zeros(5 * B, dtype=torch.uint8, device="cuda")
+        assert c.sharded_fetch_decode_async(hc.ptr, len(blob), 0, 1, d_streams, d_out) == 500_000
+        torch.cuda.synchronize()
+        assert c.status() == 0
+        for k in range(5):
+            assert bytes(d_out[k * B:k * B + 100_000].cpu().numpy()) == bytes(other[k * 100_000:(k + 1) * 100_000])
+    finally:
+        c.close()
+        hc.close()
+
+
+def test_multi_workgroup_decode_beside_a_long_encode(tsq, oracle):
+    """The multi-workgroup decoders hand chunk records from a block's PARSE workgroup(s) to its COPY workgroup and so need them
+    resident together (tsq_dec_duo.cuh).  Here a 30-block container is decoded on one context while a 2 GiB encode (512 blocks:
+    several rounds of workgroups that fill every CU) runs on another context and stream: the decode's workgroups are dispatched
+    piecemeal as CUs come free.  Bytes must be right and nothing may stall into the waits' bound."""
+    import time
+    import torch
+    B = 1 << 22
+    big = to_dev(tsq.synth.text(512 * B, seed=81))
+    small_host = tsq.synth.text(30 * B, seed=82)
+    small = to_dev(small_host)
+    enc, dec = tsq.DeviceCodec(0), tsq.DeviceCodec(0)
+    try:
+        blob = dec.compress(small, 0).clone()
+        big_out = torch.empty(tsq.container_bound(big.numel()), dtype=torch.uint8, device="cuda")
+        enc.compress(big[:8 * B], 0)                                         # (scratch allocated, kernels loaded)
+        s_enc, s_dec = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        for dv in (0, 5, 6):                                                 # default (three workgroups at 30 blocks), always three, always two
+            dec.set_variant(0, dv)
+            back = torch.empty(30 * B, dtype=torch.uint8, device="cuda")
+            t0 = time.perf_counter()
+            with torch.cuda.stream(s_enc):
+                enc.compress_async(big, 0, big_out)
+            with torch.cuda.stream(s_dec):
+                for _ in range(4):                                           # several decodes while the encode is in flight
+                    dec.decompress_async(blob, 30, back)
+            s_dec.synchronize()
+            t_dec = time.perf_counter() - t0
+            _, status = dec.last_size_status()
+            s_enc.synchronize()
+            assert status == 0, (dv, status)
+            assert torch.equal(back, small), dv
+            assert t_dec < 3.0, f"variant {dv}: four 30-block decodes beside the encode took {t_dec:.2f} s"
+    finally:
+        enc.close()
+        dec.close()
+
+
+def test_bench_sharded_path_over_rccl_with_one_rank(tsq):
+    """bench.py's N > 1 step -- process group on the nccl (= RCCL) backend, all-gather of the sizes on the GPU, one host container in
+    /dev/shm registered with hipHostRegister, tsqa_sharded_place_async, tsqa_sharded_fetch_decode_async -- executed with a world of
+    ONE rank (the box has one GPU); the host-gathered container is compared with the oracle's inside bench.py."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TSQ_BENCH_FORCE_SHARDED="1", TSQ_BENCH_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533",
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--size", "300000000", "--no-weak"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["container_equals_oracle"] is True and line["config"]["collective_backend"] == "nccl"
+    assert line["rank0_step_breakdown_ms"]["size_gather"] > 0

@@ -136,7 +136,9 @@ def lib(ab=False) -> C.CDLL:
     L.tsqa_sharded_place_async.restype = C.c_int
     L.tsqa_sharded_place_async.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, u64p, vp]
     L.tsqa_sharded_fetch_decode_async.restype = C.c_int
-    L.tsqa_sharded_fetch_decode_async.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp, vp, u64p, vp]
+    L.tsqa_sharded_fetch_decode_async.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp, C.c_size_t, vp, u64p, vp]
+    L.tsqa_copy_probe_shape.restype = C.c_char_p
+    L.tsqa_copy_probe_shape.argtypes = [vp]
     L.tsqa_measure_copy.restype = C.c_int
     L.tsqa_measure_copy.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.tsqCompress.restype = None
@@ -219,6 +221,10 @@ class DeviceCodec:
             raise self._err(rc)
         return best.value, med.value
 
+    def copy_probe_shape(self) -> str:
+        """Which launch shape the last measure_copy chose."""
+        return self.L.tsqa_copy_probe_shape(self.h).decode()
+
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -260,8 +266,8 @@ class DeviceCodec:
     def sharded_fetch_decode_async(self, host_ptr: int, container_size: int, rank: int, world: int, d_streams, d_out) -> int:
         """-> the job's uncompressed size (from the container header)."""
         total = C.c_uint64(0)
-        rc = self.L.tsqa_sharded_fetch_decode_async(self.h, host_ptr, container_size, rank, world, d_streams.data_ptr(), d_out.data_ptr(),
-                                                    self._status.data_ptr(), C.byref(total), self._stream())
+        rc = self.L.tsqa_sharded_fetch_decode_async(self.h, host_ptr, container_size, rank, world, d_streams.data_ptr(), d_streams.numel(),
+                                                    d_out.data_ptr(), d_out.numel(), self._status.data_ptr(), C.byref(total), self._stream())
         if rc:
             raise self._err(rc)
         return int(total.value)

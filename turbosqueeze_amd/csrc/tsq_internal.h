@@ -22,7 +22,12 @@ struct tsqa_ctx {
     tsq::FrameInfo* frames = nullptr;  // n_blocks frame descriptors (decode)
     uint16_t* tables = nullptr;        // n_blocks x 2^17 u16 position tables of the encoders
     size_t cap_blocks = 0, cap_tables = 0, cap_slots = 0;
-    std::vector<tsq::FrameInfo> host_frames;   // frame descriptors built on the host (sharded fetch + decode)
+    tsq::FrameInfo* host_frames = nullptr;     // frame descriptors built on the host (sharded fetch + decode): pinned
+    size_t cap_host_frames = 0;
+    std::vector<uint64_t> host_frame_src;      // where each owned frame's stream starts in the host container
+    hipEvent_t host_frames_copied = nullptr;   // recorded behind the descriptors' copy to the device
+    bool host_frames_pending = false;
+    char probe_shape[160] = {0};               // what tsqa_measure_copy chose (tsqa_copy_probe_shape)
     uint32_t* duo_ring = nullptr;      // two-workgroup decoder: chunk records handed from the PARSE to the COPY workgroup of a block
     uint32_t* duo_flags = nullptr;     // and their progress counters
     size_t cap_duo = 0;
@@ -43,6 +48,7 @@ struct tsqa_ctx {
     void set_error(const char* fmt, ...) __attribute__((format(printf, 2, 3)));
     int reserve(size_t n_blocks, bool want_tables, bool want_slots = true);
     int reserve_duo(size_t n_blocks);
+    int reserve_host_frames(size_t n);
     // `readable` >= n: bytes of d_in that may be read (look-ahead halo); zeros are seen beyond it
     int launch_encode(const void* d_in, size_t n, size_t readable, uint32_t ext, int32_t* status, hipStream_t s);
     // general form: block b at d_in + b * stride, streams to slots_out[b * TSQ_OUTPUT_SZ], sizes to sizes_out[b]

@@ -1,9 +1,9 @@
 // tsq_launch.cuh -- kernel selection and launch for the device context.
 //
-// The product library carries three kernel families: the five-wave staged encoder (tsq_enc_stage.cuh, standard and lean
-// layouts, with and without extensions), the byte-lane decoder (tsq_dec_sym.cuh) and the serial correctness baselines
-// (tsq_serial.cuh, variant 1).  The superseded generations (ab/: encoder variants 2-5, decoder variants 2, 8, 9) are compiled only
-// into the A/B library (`make ab`, -DTSQ_AB_VARIANTS), which tests/test_gpu_parity.py holds against the same oracle.
+// The product library carries three kernel families: the twelve-wave staged encoder (tsq_enc_stage.cuh, standard and lean
+// layouts, with and without extensions), the byte-lane decoder (tsq_dec_sym.cuh, tsq_dec_duo.cuh) and the serial correctness
+// baselines (tsq_serial.cuh, variant 1).  The previous round's production encoder (ab/tsq_enc_stage_r03.cuh, encoder variant 5) is
+// compiled only into the A/B library (`make ab`, -DTSQ_AB_VARIANTS), which tests/test_gpu_parity.py holds against the same oracle.
 #pragma once
 
 #include <atomic>
@@ -16,8 +16,7 @@
 #include "tsq_dec_duo.cuh"
 #include "tsq_enc_stage.cuh"
 #ifdef TSQ_AB_VARIANTS
-#include "ab/tsq_dec_ring.cuh"
-#include "ab/tsq_enc_stage5.cuh"
+#include "ab/tsq_enc_stage_r03.cuh"
 #endif
 
 namespace tsq {
@@ -59,18 +58,18 @@ inline int launch_encode_kernels(tsqa_ctx* c, const uint8_t* in, size_t n, size_
         return 0;
     }
 #ifdef TSQ_AB_VARIANTS
-    if (v == 5) {                       // round 2's five-wave staged encoder, frozen (ab/tsq_enc_stage5.cuh)
+    if (v == 5) {                       // round 3's production encoder, frozen (ab/tsq_enc_stage_r03.cuh)
         static std::atomic<uint64_t> ab_devices{0};
-        const void* const fns[4] = {reinterpret_cast<const void*>(r02::enc_stage_kernel<true, true>), reinterpret_cast<const void*>(r02::enc_stage_kernel<false, true>),
-                                    reinterpret_cast<const void*>(r02::enc_stage_kernel<true, false>), reinterpret_cast<const void*>(r02::enc_stage_kernel<false, false>)};
-        const uint32_t bytes[4] = {r02::StageCfg::total, r02::StageCfg::total, r02::StageCfg::total_lean, r02::StageCfg::total_lean};
+        const void* const fns[4] = {reinterpret_cast<const void*>(r03::enc_stage_kernel<true, true>), reinterpret_cast<const void*>(r03::enc_stage_kernel<false, true>),
+                                    reinterpret_cast<const void*>(r03::enc_stage_kernel<true, false>), reinterpret_cast<const void*>(r03::enc_stage_kernel<false, false>)};
+        const uint32_t bytes[4] = {r03::StageCfgT<true>::total, r03::StageCfgT<true>::total, r03::StageCfgT<false>::total, r03::StageCfgT<false>::total};
         if (int rc = raise_lds_limit(c, ab_devices, fns, bytes)) return rc;
         if (nb > (uint32_t)c->n_cus) {
-            if (ext) TSQ_LAUNCH_ENC((r02::enc_stage_kernel<true, false>), 320, r02::StageCfg::total_lean);
-            else     TSQ_LAUNCH_ENC((r02::enc_stage_kernel<false, false>), 320, r02::StageCfg::total_lean);
+            if (ext) TSQ_LAUNCH_ENC((r03::enc_stage_kernel<true, false>), r03::StageCfgT<false>::THREADS_LEAN, r03::StageCfgT<false>::total);
+            else     TSQ_LAUNCH_ENC((r03::enc_stage_kernel<false, false>), r03::StageCfgT<false>::THREADS_LEAN, r03::StageCfgT<false>::total);
         } else {
-            if (ext) TSQ_LAUNCH_ENC((r02::enc_stage_kernel<true, true>), 320, r02::StageCfg::total);
-            else     TSQ_LAUNCH_ENC((r02::enc_stage_kernel<false, true>), 320, r02::StageCfg::total);
+            if (ext) TSQ_LAUNCH_ENC((r03::enc_stage_kernel<true, true>), r03::StageCfgT<true>::THREADS, r03::StageCfgT<true>::total);
+            else     TSQ_LAUNCH_ENC((r03::enc_stage_kernel<false, true>), r03::StageCfgT<true>::THREADS, r03::StageCfgT<true>::total);
         }
         return 0;
     }
@@ -78,8 +77,8 @@ inline int launch_encode_kernels(tsqa_ctx* c, const uint8_t* in, size_t n, size_
     if (v == 5) { c->set_error("kernel variant %d lives in the A/B library only (make ab)", v); return TSQA_ERR_ARG; }
 #endif
     if (v >= 2 && v <= 4) { c->set_error("kernel variant %d is not built", v); return TSQA_ERR_ARG; }
-    // five-wave staged pipeline: scan + match + orbit + parser + builder.  More blocks than CUs: the lean layout (no input
-    // window in LDS, candidate bytes from L2) lets two blocks share a CU; each is a little slower, together they are faster.
+    // twelve-wave staged pipeline (tsq_enc_stage.cuh).  More blocks than CUs: the lean layout (no input window in LDS, candidate
+    // bytes from L2) lets several blocks share a CU; each is a little slower, together they are faster.
     const bool lean = v == 6 || (v == 0 && nb > (uint32_t)c->n_cus);
     if (lean) {
         if (ext) TSQ_LAUNCH_ENC((enc_stage_kernel<true, false>), StageCfgT<false>::THREADS_LEAN, StageCfgT<false>::total);
@@ -103,21 +102,7 @@ inline int launch_decode_kernels(tsqa_ctx* c, const uint8_t* container, const Fr
     }
     const int v = c->dec_variant;
     if (v == 1) { hipLaunchKernelGGL(dec_serial_kernel, dim3(n_blocks), dim3(64), 0, s, container, frames, out, status); return 0; }
-#ifdef TSQ_AB_VARIANTS
-    if (v == 8 || v == 9) {
-        static std::atomic<uint64_t> ab_devices{0};
-        const void* const fns[2] = {reinterpret_cast<const void*>(dec_ring_kernel<true>), reinterpret_cast<const void*>(dec_ring_kernel<false>)};
-        const uint32_t bytes[2] = {RingLds::total, LeanLds::total};
-        if (int rc = raise_lds_limit(c, ab_devices, fns, bytes)) return rc;
-        if (v == 8)        // byte-granular copies, history ring in LDS (round 1's default)
-            hipLaunchKernelGGL(dec_ring_kernel<true>, dim3(n_blocks), dim3(RingCfg::T), RingLds::total, s, container, frames, out, status);
-        else               // the same without the ring: two blocks per CU
-            hipLaunchKernelGGL(dec_ring_kernel<false>, dim3(n_blocks), dim3(LeanCfg::T), LeanLds::total, s, container, frames, out, status);
-        return 0;
-    }
-#else
-    if (v == 8 || v == 9) { c->set_error("kernel variant %d lives in the A/B library only (make ab)", v); return TSQA_ERR_ARG; }
-#endif
+    if (v == 8 || v == 9) { c->set_error("kernel variant %d is not built", v); return TSQA_ERR_ARG; }
     // Few blocks (at most half as many as CUs: every GPU of a multi-GPU job on enwik9): two workgroups per block, one for each of
     // the block's two serial chains (tsq_dec_duo.cuh).
     // Few blocks (every GPU of a multi-GPU job on enwik9): several workgroups per block on different CUs of one XCD -- the block's

@@ -79,6 +79,8 @@ extern "C" void tsqa_destroy(tsqa_ctx* c)
     (void)hipFree(c->slots); (void)hipFree(c->tables); (void)hipFree(c->sizes); (void)hipFree(c->frame_at);
     (void)hipFree(c->frames); (void)hipFree(c->d_size); (void)hipFree(c->d_status);
     (void)hipFree(c->duo_ring); (void)hipFree(c->duo_flags);
+    if (c->host_frames) (void)hipHostFree(c->host_frames);
+    if (c->host_frames_copied) (void)hipEventDestroy(c->host_frames_copied);
     delete c;
 }
 
@@ -128,6 +130,24 @@ int tsqa_ctx::reserve_duo(size_t n_blocks)
     TSQ_HIP(this, hipMalloc(&duo_ring, n_blocks * (size_t)DuoCfg::SLOTS * DuoCfg::REC_WORDS * sizeof(uint32_t)));
     TSQ_HIP(this, hipMalloc(&duo_flags, n_blocks * (size_t)DuoCfg::FLAG_STRIDE * sizeof(uint32_t)));
     cap_duo = n_blocks;
+    return TSQA_OK;
+}
+
+// Frame descriptors built on the host (sharded fetch + decode): pinned, so that their copy to the device is a DMA ordered on the
+// caller's stream; the previous call's copy is waited for before they are overwritten.
+int tsqa_ctx::reserve_host_frames(size_t n)
+{
+    (void)hipSetDevice(device);
+    if (host_frames_pending) { (void)hipEventSynchronize(host_frames_copied); host_frames_pending = false; }
+    if (!host_frames_copied) TSQ_HIP(this, hipEventCreateWithFlags(&host_frames_copied, hipEventDisableTiming));
+    if (n > cap_host_frames) {
+        if (host_frames) (void)hipHostFree(host_frames);
+        host_frames = nullptr; cap_host_frames = 0;
+        size_t want = 64; while (want < n) want *= 2;
+        TSQ_HIP(this, hipHostMalloc(reinterpret_cast<void**>(&host_frames), want * sizeof(FrameInfo), hipHostMallocDefault));
+        cap_host_frames = want;
+    }
+    host_frame_src.resize(cap_host_frames);
     return TSQA_OK;
 }
 
@@ -456,11 +476,17 @@ extern "C" int tsqa_sharded_place_async(tsqa_ctx* c, const void* d_slots, const 
     hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
     (void)hipSetDevice(c->device);
     uint8_t* base = static_cast<uint8_t*>(host_container);
+    // every size and the capacity are checked before anything is written or enqueued (no partial container on an error)
     uint64_t at = 16;
     for (uint32_t b = 0; b < n_blocks; ++b) {
         const uint32_t sz = all_sizes[b];
         if (sz < 3 || sz > kSlotSize) { c->set_error("sharded_place: block %u has size %u", b, sz); return TSQA_ERR_ARG; }
-        if (at + 3ull + sz > host_cap) { c->set_error("sharded_place: the host container is too small"); return TSQA_ERR_ARG; }
+        at += 3ull + sz;
+    }
+    if (at > host_cap) { c->set_error("sharded_place: the host container is too small (%llu > %zu)", (unsigned long long)at, host_cap); return TSQA_ERR_ARG; }
+    at = 16;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        const uint32_t sz = all_sizes[b];
         if (b % world == rank) {
             const uint32_t frame = sz | (ext ? 0x800000u : 0u);                          // tsq_threads.cpp:218-219
             uint8_t* p = base + at;
@@ -479,7 +505,8 @@ extern "C" int tsqa_sharded_place_async(tsqa_ctx* c, const void* d_slots, const 
 // The reader's side: walk the container's frames (host memory), bring this rank's frames to d_streams (frame k of the rank at
 // k * TSQ_OUTPUT_SZ) and decode them back to back into d_out (block k of the rank at k * TSQ_BLOCK_SZ).
 extern "C" int tsqa_sharded_fetch_decode_async(tsqa_ctx* c, const void* host_container, size_t container_size, uint32_t rank, uint32_t world,
-                                               void* d_streams, void* d_out, int32_t* d_status, uint64_t* total, void* hip_stream)
+                                               void* d_streams, size_t streams_cap, void* d_out, size_t out_cap, int32_t* d_status, uint64_t* total,
+                                               void* hip_stream)
 {
     if (!c) return TSQA_ERR_ARG;
     if (!host_container || !d_streams || !d_out || !d_status || !total || world == 0 || rank >= world) { c->set_error("sharded_fetch_decode: bad argument"); return TSQA_ERR_ARG; }
@@ -491,8 +518,12 @@ extern "C" int tsqa_sharded_fetch_decode_async(tsqa_ctx* c, const void* host_con
     memcpy(&nb, p + 4, 4); memcpy(&tot, p + 8, 8);
     if (nb == 0 || (size_t)nb > (container_size - 16) / 6) { c->set_error("sharded_fetch_decode: bad block count"); return TSQA_ERR_FORMAT; }
     const uint32_t n_local = nb > rank ? (nb - rank + world - 1) / world : 0;
+    // The container is not trusted: the whole frame walk is validated -- against the container's own size and against what the caller's
+    // buffers can hold -- before a single copy is enqueued (a container with more, shorter blocks than the job the buffers were sized
+    // for must not overrun them).
+    if ((uint64_t)n_local * kSlotSize > streams_cap) { c->set_error("sharded_fetch_decode: %u owned frames do not fit d_streams (%zu B)", n_local, streams_cap); return TSQA_ERR_FORMAT; }
     if (int rc = c->reserve(n_local ? n_local : 1, false, false)) return rc;
-    c->host_frames.resize(n_local ? n_local : 1);
+    if (int rc = c->reserve_host_frames(n_local ? n_local : 1)) return rc;
     uint64_t at = 16, sum = 0;
     for (uint32_t b = 0; b < nb; ++b) {
         if (at + 6 > container_size) { c->set_error("sharded_fetch_decode: truncated container"); return TSQA_ERR_FORMAT; }
@@ -503,10 +534,11 @@ extern "C" int tsqa_sharded_fetch_decode_async(tsqa_ctx* c, const void* host_con
         if (usize > kBlockSize) { c->set_error("sharded_fetch_decode: bad block size in frame %u", b); return TSQA_ERR_FORMAT; }
         if (b % world == rank) {
             const uint32_t k = b / world;
-            TSQ_HIP(c, hipMemcpyAsync(static_cast<uint8_t*>(d_streams) + (size_t)k * kSlotSize, p + at + 3, len, hipMemcpyHostToDevice, s));
+            if ((uint64_t)k * kBlockSize + usize > out_cap) { c->set_error("sharded_fetch_decode: owned block %u does not fit d_out (%zu B)", k, out_cap); return TSQA_ERR_FORMAT; }
             FrameInfo f;
             f.stream_at = (uint64_t)k * kSlotSize; f.out_at = (uint64_t)k * kBlockSize; f.stream_len = len; f.ext = frame >> 23; f.out_len = usize; f.pad = 0;
             c->host_frames[k] = f;
+            c->host_frame_src[k] = at + 3;
         }
         sum += usize;
         at += 3ull + len;
@@ -515,7 +547,13 @@ extern "C" int tsqa_sharded_fetch_decode_async(tsqa_ctx* c, const void* host_con
     *total = tot;
     TSQ_HIP(c, hipMemsetAsync(d_status, 0, sizeof(int32_t), s));
     if (n_local == 0) return TSQA_OK;
-    TSQ_HIP(c, hipMemcpyAsync(c->frames, c->host_frames.data(), (size_t)n_local * sizeof(FrameInfo), hipMemcpyHostToDevice, s));
+    for (uint32_t k = 0; k < n_local; ++k)
+        TSQ_HIP(c, hipMemcpyAsync(static_cast<uint8_t*>(d_streams) + (size_t)k * kSlotSize, p + c->host_frame_src[k], c->host_frames[k].stream_len, hipMemcpyHostToDevice, s));
+    // (the descriptors live in pinned memory: the copy is a real DMA ordered on `s`, and reserve_host_frames has waited for the
+    //  previous call's copy before they were overwritten)
+    TSQ_HIP(c, hipMemcpyAsync(c->frames, c->host_frames, (size_t)n_local * sizeof(FrameInfo), hipMemcpyHostToDevice, s));
+    TSQ_HIP(c, hipEventRecord(c->host_frames_copied, s));
+    c->host_frames_pending = true;
     return c->launch_decode_frames(d_streams, c->frames, n_local, d_out, d_status, s);
 }
 
@@ -600,13 +638,15 @@ extern "C" int tsqa_measure_copy(tsqa_ctx* c, size_t bytes, int reps, double* be
         for (int i = 1; i < reps; ++i) for (int j = i; j > 0 && rates[j] < rates[j - 1]; --j) { double t = rates[j]; rates[j] = rates[j - 1]; rates[j - 1] = t; }
         if (best_gbps) *best_gbps = rates[reps - 1];
         if (median_gbps) *median_gbps = rates[reps / 2];
-        c->set_error("copy probe: mode %d (0 grid-stride, 1 grid-stride non-temporal, 2 one pass non-temporal), %u workgroups", mode, mode == 2 ? (uint32_t)((words + 1023u) / 1024u) : grid);
+        snprintf(c->probe_shape, sizeof(c->probe_shape), "copy probe: mode %d (0 grid-stride, 1 grid-stride non-temporal, 2 one pass non-temporal), %u workgroups", mode, mode == 2 ? (uint32_t)((words + 1023u) / 1024u) : grid);
     } else c->set_error("copy probe failed");
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     (void)hipFree(a); (void)hipFree(b);
     return rc;
 }
+
+extern "C" const char* tsqa_copy_probe_shape(const tsqa_ctx* c) { return c ? c->probe_shape : ""; }
 
 #ifdef TSQ_SPINS
 extern "C" int tsqa_debug_spins(uint32_t* out16)

@@ -261,6 +261,8 @@ class DeviceBlocks:
 
     def fetch_decode(self, host, container_size, layout, d_out) -> int:
         """Frame walk, owned frames to the device, decode (tsqa_sharded_fetch_decode_async).  -> uncompressed size of the job."""
+        if container_size > host.size:
+            raise ValueError(f"container size {container_size} exceeds the host mapping ({host.size} B)")
         return self.codec.sharded_fetch_decode_async(host.ptr, container_size, layout.rank, layout.world, self.slots, d_out)
 
     def sync(self):
@@ -302,7 +304,7 @@ class ShardedCodec:
     def _gather_sizes(self, mine):
         import numpy as np
         lay = self.layout
-        if lay.world == 1:
+        if lay.world == 1 and not getattr(self, "always_gather", False):
             return np.ascontiguousarray(mine.cpu().numpy().astype(np.uint32)[:lay.n_local])
         import torch
         import torch.distributed as dist
