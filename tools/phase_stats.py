@@ -44,6 +44,7 @@ print("  COMMIT  total=%.0f waited=%.0f busy=%.0f" % (e[46] / T, e[45] / T, (e[4
 print("  ORBIT   total=%.0f waited=%.0f busy=%.0f" % (e[7] / T, e[6] / T, (e[7] - e[6]) / T))
 print("  lag loop (even tiles): WALK publishes tile t-3 -> MATCH publishes tile t: %.0f cycles -> ORBIT publishes tile t: %.0f cycles" % (e[51] / max(e[52], 1), e[53] / max(e[54], 1)))
 print("  WALK    total=%.0f waited(orbit)=%.0f waited(events)=%.0f waited(answers)=%.0f busy=%.0f  queries per tile=%.3f" % (e[10] / T, e[8] / T, e[9] / T, e[40] / T, (e[10] - e[8] - e[9] - e[40]) / T, e[20] / T))
+print("          short way through the tile: %.3f of the tiles; ORBIT: tiles with a late classification %.3f, orbits computed again %.3f" % (e[59] / T, 2 * e[57] / T, 2 * e[58] / T))
 print("  ACCOUNT total=%.0f waited(events)=%.0f waited(queue)=%.0f busy=%.0f  tiles with events=%.3f" % (e[43] / T, e[41] / T, e[42] / T, (e[43] - e[41] - e[42]) / T, e[44] / T))
 
 print("  BUILDER total=%.0f waited=%.0f (ring %.0f) busy=%.0f" % (e[18] / T, e[17] / T, e[37] / T, (e[18] - e[17]) / T))

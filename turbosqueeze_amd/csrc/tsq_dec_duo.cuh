@@ -287,7 +287,11 @@ __device__ __forceinline__ void duo_parse(const uint8_t* __restrict__ in, uint32
                 rec[4] = (last_chunk ? DuoCfg::kLast : 0u) | (bad ? DuoCfg::kError : 0u);
                 rec[5] = cut_short ? W : W + C::S;                            // where the next record's window starts (for the COPY side's prefetch)
             }
-            __syncthreads();                                 // every thread's record stores are complete (the barrier waits for them) ...
+            // Every thread that stored part of the record makes its own stores visible at agent scope before the barrier: the
+            // workgroup-scope fence of __syncthreads() does not wait for global stores (no s_waitcnt vmcnt(0)), so without this
+            // another wave's record words could still be in flight when thread 0's flag becomes visible to the COPY workgroup.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
             if (tid == 0) duo_store_release(flags, rec_no + 1u);            // ... and thread 0 publishes them
             if (bad) { if (tid == 0) atomicMax(status, kErrStream); return; }
             if (last_chunk) return;

@@ -103,23 +103,34 @@ inline int launch_decode_kernels(tsqa_ctx* c, const uint8_t* container, const Fr
     const int v = c->dec_variant;
     if (v == 1) { hipLaunchKernelGGL(dec_serial_kernel, dim3(n_blocks), dim3(64), 0, s, container, frames, out, status); return 0; }
     if (v == 8 || v == 9) { c->set_error("kernel variant %d is not built", v); return TSQA_ERR_ARG; }
-    // Few blocks (at most half as many as CUs: every GPU of a multi-GPU job on enwik9): two workgroups per block, one for each of
-    // the block's two serial chains (tsq_dec_duo.cuh).
     // Few blocks (every GPU of a multi-GPU job on enwik9): several workgroups per block on different CUs of one XCD -- the block's
     // copy chain on one, its parse on one (at most half as many blocks as CUs) or two (at most a third) (tsq_dec_duo.cuh).
-    const bool trio = v == 5 || ((v == 0 || v == 3) && 3u * n_blocks <= (uint32_t)c->n_cus);
-    if (trio || v == 3 || v == 6 || (v == 0 && 2u * n_blocks <= (uint32_t)c->n_cus)) {
+    auto launch_multi = [&](const FrameInfo* fr, uint32_t nblk, bool three) -> int {
         static std::atomic<uint64_t> duo_devices{0};
         const void* const fns[2] = {reinterpret_cast<const void*>(dec_duo_kernel<1>), reinterpret_cast<const void*>(dec_duo_kernel<2>)};
         const uint32_t lds_bytes = DuoCopyLds::total > SymLds::total ? DuoCopyLds::total : SymLds::total;
         const uint32_t bytes[2] = {lds_bytes, lds_bytes};
         if (int rc = raise_lds_limit(c, duo_devices, fns, bytes)) return rc;
-        if (int rc = c->reserve_duo(n_blocks)) return rc;
-        if (hipMemsetAsync(c->duo_flags, 0, (size_t)n_blocks * DuoCfg::FLAG_STRIDE * sizeof(uint32_t), s) != hipSuccess) { c->set_error("hipMemsetAsync failed"); return TSQA_ERR_HIP; }
-        const uint32_t groups = (n_blocks + 7u) / 8u;
-        if (trio && v != 6) hipLaunchKernelGGL(dec_duo_kernel<2>, dim3(24u * groups), dim3(SymCfg::T), lds_bytes, s, container, frames, n_blocks, out, status, c->duo_ring, c->duo_flags);
-        else hipLaunchKernelGGL(dec_duo_kernel<1>, dim3(16u * groups), dim3(SymCfg::T), lds_bytes, s, container, frames, n_blocks, out, status, c->duo_ring, c->duo_flags);
+        if (int rc = c->reserve_duo(nblk)) return rc;
+        if (hipMemsetAsync(c->duo_flags, 0, (size_t)nblk * DuoCfg::FLAG_STRIDE * sizeof(uint32_t), s) != hipSuccess) { c->set_error("hipMemsetAsync failed"); return TSQA_ERR_HIP; }
+        const uint32_t groups = (nblk + 7u) / 8u;
+        if (three) hipLaunchKernelGGL(dec_duo_kernel<2>, dim3(24u * groups), dim3(SymCfg::T), lds_bytes, s, container, fr, nblk, out, status, c->duo_ring, c->duo_flags);
+        else hipLaunchKernelGGL(dec_duo_kernel<1>, dim3(16u * groups), dim3(SymCfg::T), lds_bytes, s, container, fr, nblk, out, status, c->duo_ring, c->duo_flags);
         return 0;
+    };
+    const uint32_t cus = (uint32_t)c->n_cus;
+    const bool trio = v == 5 || ((v == 0 || v == 3) && 3u * n_blocks <= cus);
+    if (trio || v == 3 || v == 6 || (v == 0 && 2u * n_blocks <= cus)) return launch_multi(frames, n_blocks, trio && v != 6);
+    // More blocks than CUs, one workgroup per block: the blocks run in rounds of n_cus, and a last round with few blocks would
+    // leave most of the chip idle for a whole block latency (321 blocks: 256 + 65).  The blocks of such a partial round get several
+    // workgroups each, in a launch of their own behind the full rounds (tsq_threads.cpp:71 deals blocks to workers the same way:
+    // whoever is free takes the next).
+    if (v == 0 && n_blocks > cus) {
+        const uint32_t tail = n_blocks % cus, full = n_blocks - tail;
+        if (tail != 0u && 2u * tail <= cus) {
+            hipLaunchKernelGGL(dec_sym_kernel, dim3(full), dim3(SymCfg::T), SymLds::total, s, container, frames, out, status);
+            return launch_multi(frames + full, tail, 3u * tail <= cus);
+        }
     }
     // one workgroup per block at any block count: with more blocks than CUs the blocks simply queue (the decoder needs its 150 KB
     // of LDS; the two-per-CU layout of the byte-granular decoder was 1.85x slower per byte, tools/config5_sweep.py)
