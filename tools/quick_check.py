@@ -102,4 +102,22 @@ if "--no-time" not in sys.argv and "--enc-only" not in sys.argv:
             line += f"  variant {dv}: {dm / max(dn, 1):.3f} ms ({len(host) / (dm / max(dn, 1)) / 1e6:.1f} GB/s)"
         codec.set_variant(0, 0)
         print(line, flush=True)
+if "--big" in sys.argv:
+    # the chip-filling regime: 4 GiB of text = 1 024 blocks (lean encoder layout, blocks queue behind each other)
+    del src, out
+    torch.cuda.empty_cache()
+    host = tsq.synth.text(4 << 30, 1)
+    src = torch.from_numpy(host).cuda()
+    out = torch.empty(api.container_bound(len(host)), dtype=torch.uint8, device="cuda")
+    for ext in (0, 1):
+        blob = codec.compress(src, ext, out)
+        back = codec.decompress(blob)
+        codec.profile_read()
+        for _ in range(2):
+            blob = codec.compress(src, ext, out)
+            back = codec.decompress(blob)
+        torch.cuda.synchronize()
+        em, en, dm, dn = codec.profile_read()
+        assert torch.equal(back, src)
+        print(f"BIG text 4 GiB ext={ext}: encode {len(host) / (em / max(en, 1)) / 1e6:.2f} GB/s ({em / max(en, 1):.2f} ms), decode {len(host) / (dm / max(dn, 1)) / 1e6:.1f} GB/s ({dm / max(dn, 1):.3f} ms)", flush=True)
 sys.exit(1 if bad else 0)

@@ -44,6 +44,8 @@ namespace tsq {
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4_t lds_u32x4_t;
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x2_t lds_u32x2_t;
 
 // WINDOW = the standard layout (one block per CU: the input window ring in LDS, ten tile records); the lean layout (two blocks per CU)
 // has no window and eight records.
@@ -52,15 +54,15 @@ struct StageCfgT {
     static constexpr uint32_t THREADS = 1024;                     // sixteen wavefronts are launched, twelve work (see the kernel)
     static constexpr uint32_t THREADS_LEAN = 768;                 // the lean layout launches the twelve working ones only
     static constexpr uint32_t EQ = 64, EV_WORDS = 4;              // events between WALK and ACCOUNT
-    static constexpr uint32_t Q = 16;                             // items between ACCOUNT and BUILDER
+    static constexpr uint32_t Q = WINDOW ? 16 : 8;                // items between ACCOUNT and BUILDER (the queue is never full: profiles/r03_encoder_spin_counts.txt)
     static constexpr uint32_t ITEM_WORDS = 80;
     static constexpr uint32_t RING = 256;                          // symbol records between BUILDER and EMIT (four batches)
     static constexpr uint32_t R = WINDOW ? 10 : 8;                // tile records in flight (every stage waits less with ten; the lean layout has room for eight)
     static constexpr uint32_t OWN_MASK = 0x7FFFu;                 // owner image: hash folded to 15 bits
-    static constexpr uint32_t WIN = 73728;                        // input window ring: the last 64 KiB of input and then some (a multiple of 64)
+    static constexpr uint32_t WIN = 71168;                        // input window ring: the last 64 KiB of input and what SCAN is ahead of MATCH (at most R tiles; a multiple of 64)
     static constexpr uint32_t W16 = 16;                           // word offset of the uint4-per-lane input words
-    static constexpr uint32_t ARR = 16 + 256;                     // word offset of the u32-per-lane arrays
-    static constexpr uint32_t REC_WORDS = ARR + 15 * 64;
+    static constexpr uint32_t ARR = 16 + 256;                     // word offset of the per-lane words: four groups of four words per lane
+    static constexpr uint32_t REC_WORDS = ARR + 16 * 64;
     static constexpr uint32_t off_owner = 0;                                   // u8[65536]
     static constexpr uint32_t off_queue = OWN_MASK + 1u;                       // u32[Q * ITEM_WORDS]
     static constexpr uint32_t off_ring = off_queue + Q * ITEM_WORDS * 4;       // u32[RING]
@@ -74,11 +76,19 @@ struct StageCfgT {
 // ctl words: 0 queue head, 1 queue tail, 2 tiles with twin masks, 3 / 35 even / odd tiles matched, 4 / 15 even / odd tiles with orbits,
 //            5 tiles walked, 6 stop, 7..9 BUILDER/EMIT (tsq_enc_builder.cuh), 10..14 WALK/ACCOUNT events, 33 tiles committed, 34 tiles hashed,
 // record: header words 0,1 = lanes that have an earlier twin inside the tile (TWINS), 2,3 = the lanes the parse visited (WALK)
-//         per-lane arrays: 0 hash  1,2 twins in this tile (earlier lanes)  3,4 twins in tile t-1  5,6 twins in tile t-2
-//                          7 spanword  8 candidate | nibble << 24  9 orbit halt  10,11 orbit mask  12,13 twins in tile t-3
-//                          14 owner word (HASH -> TWINS), then the nearest twin's word (NEAR -> WALK)
+//         per-lane words, in four groups of four: group g of lane l is the 16-byte LDS word at ARR + g * 256 + l * 4, so that a stage
+//         reads or writes a whole group (or half of one) with ONE LDS instruction -- the LDS pipe is what the twelve wavefronts share,
+//         and a 4-byte access per lane costs it as much as an 8-byte one and half of a 16-byte one:
+//           A: spanword | candidate | nibble << 24 | orbit halt | orbit mask lo        (MATCH, ORBIT -> WALK, ACCOUNT)
+//           B: orbit mask hi | nearest twin's word (NEAR) | twins in this tile (earlier lanes) lo, hi
+//           C: twins in tile t-1 lo, hi | twins in tile t-2 lo, hi                     (TWINS -> NEAR, MATCH, ORBIT, WALK)
+//           D: hash | twins in tile t-3 lo, hi | owner word (HASH -> TWINS)
 // spanword: natural span (bits 0..7) | hard (8) | has a twin (9) | certain match (10) | near twin (11) | twins of t-2 settled (12) | common prefix (16..23)
-enum : uint32_t { kAH = 0, kATin = 1, kATp1 = 3, kATp2 = 5, kASpan = 7, kALane = 8, kANx = 9, kAOrb = 10, kATp3 = 12, kAOwn = 14 };
+enum : uint32_t { kGA = 0, kGB = 256, kGC = 512, kGD = 768 };
+__device__ __forceinline__ u32x4_t lds_ld4(volatile lds_u32_t* p) { return *(volatile lds_u32x4_t*)p; }
+__device__ __forceinline__ u32x2_t lds_ld2(volatile lds_u32_t* p) { return *(volatile lds_u32x2_t*)p; }
+__device__ __forceinline__ void lds_st4(volatile lds_u32_t* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { u32x4_t v; v.x = a; v.y = b; v.z = c; v.w = d; *(volatile lds_u32x4_t*)p = v; }
+__device__ __forceinline__ void lds_st2(volatile lds_u32_t* p, uint32_t a, uint32_t b) { u32x2_t v; v.x = a; v.y = b; *(volatile lds_u32x2_t*)p = v; }
 // events between WALK and ACCOUNT, and their ctl words (10 events produced, 11 consumed, 12 queries answered, 13 the answer,
 // 14 the tile ACCOUNT works on: the tiles before it are accounted)
 enum : uint32_t { kEvSeg = 1, kEvHaz = 2, kEvEnd = 3 };
@@ -242,9 +252,9 @@ __device__ __forceinline__ void stage_hash(const uint8_t* src, uint64_t avail, u
                 if (wbase == 0u && lane < 32u) *(volatile lds_u32x4_t*)(lds + StageCfg::off_win + StageCfg::WIN + lane) = v;
             }
         }
-        volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
-        arr[kAH * 64] = h;
-        arr[kAOwn * 64] = before | (id << 8) | (after != tag ? 0x1000u : 0u);     // owner before | this tile's id | another lane of the tile took the bucket
+        volatile lds_u32_t* arr = rec + StageCfg::ARR + lane * 4u;
+        // group D: hash | (twins in t-3: TWINS) | owner before | this tile's id | another lane of the tile took the bucket
+        lds_st4(arr + kGD, h, 0u, 0u, before | (id << 8) | (after != tag ? 0x1000u : 0u));
         TSQ_TRACE(1, t);
         TSQ_DELAY(0);
         stage_publish(ctl, kCtlHashed, t + 1u, lane);
@@ -290,9 +300,9 @@ __device__ __forceinline__ void stage_twins(uint32_t n, lds_u8_t* lds, uint32_t 
         volatile lds_u32_t* rec_m1 = recs + ((t + StageCfg::R - 1u) % StageCfg::R) * StageCfg::REC_WORDS;
         volatile lds_u32_t* rec_m2 = recs + ((t + StageCfg::R - 2u) % StageCfg::R) * StageCfg::REC_WORDS;
         volatile lds_u32_t* rec_m3 = recs + ((t + StageCfg::R - 3u) % StageCfg::R) * StageCfg::REC_WORDS;
-        volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
-        const uint32_t h = arr[kAH * 64];
-        const uint32_t own = arr[kAOwn * 64];
+        volatile lds_u32_t* arr = rec + StageCfg::ARR + lane * 4u;
+        const u32x4_t gd = lds_ld4(arr + kGD);
+        const uint32_t h = gd.x, own = gd.w;
         const uint32_t before = own & 0xFFu;
         const uint32_t id = (own >> 8) & 3u;
         const uint32_t id_m1 = id == 1u ? 3u : id - 1u; // the id of tile t-1 (the third one is tile t-2's)
@@ -306,11 +316,13 @@ __device__ __forceinline__ void stage_twins(uint32_t n, lds_u8_t* lds, uint32_t 
             const uint32_t q = before & 63u;
             const uint32_t bid = before >> 6;
             const bool in_p1 = bid == id_m1, in_p3 = bid == id;
-            volatile lds_u32_t* qa = (in_p1 ? rec_m1 : in_p3 ? rec_m3 : rec_m2) + StageCfg::ARR + q;
-            const uint32_t hq = qa[kAH * 64];
-            const uint64_t q_in = (uint64_t)qa[kATin * 64] | ((uint64_t)qa[(kATin + 1) * 64] << 32);
-            const uint64_t q_p1 = (uint64_t)qa[kATp1 * 64] | ((uint64_t)qa[(kATp1 + 1) * 64] << 32);
-            const uint64_t q_p2 = (uint64_t)qa[kATp2 * 64] | ((uint64_t)qa[(kATp2 + 1) * 64] << 32);
+            volatile lds_u32_t* qa = (in_p1 ? rec_m1 : in_p3 ? rec_m3 : rec_m2) + StageCfg::ARR + q * 4u;
+            const uint32_t hq = qa[kGD];
+            const u32x2_t qi = lds_ld2(qa + kGB + 2u);
+            const u32x4_t qc = lds_ld4(qa + kGC);
+            const uint64_t q_in = (uint64_t)qi.x | ((uint64_t)qi.y << 32);
+            const uint64_t q_p1 = (uint64_t)qc.x | ((uint64_t)qc.y << 32);
+            const uint64_t q_p2 = (uint64_t)qc.z | ((uint64_t)qc.w << 32);
             const bool same = before != 0u && hq == h;
             unsure = before != 0u && hq != h;
             const uint64_t chain = q_in | (1ull << q);
@@ -346,10 +358,9 @@ __device__ __forceinline__ void stage_twins(uint32_t n, lds_u8_t* lds, uint32_t 
             }
         }
         if (lane == 0) { rec[0] = (uint32_t)twins_here; rec[1] = (uint32_t)(twins_here >> 32); }
-        arr[kATin * 64] = (uint32_t)twin_in;  arr[(kATin + 1) * 64] = (uint32_t)(twin_in >> 32);
-        arr[kATp1 * 64] = (uint32_t)twin_p1;  arr[(kATp1 + 1) * 64] = (uint32_t)(twin_p1 >> 32);
-        arr[kATp2 * 64] = (uint32_t)twin_p2;  arr[(kATp2 + 1) * 64] = (uint32_t)(twin_p2 >> 32);
-        arr[kATp3 * 64] = (uint32_t)twin_p3;  arr[(kATp3 + 1) * 64] = (uint32_t)(twin_p3 >> 32);
+        lds_st2(arr + kGB + 2u, (uint32_t)twin_in, (uint32_t)(twin_in >> 32));
+        lds_st4(arr + kGC, (uint32_t)twin_p1, (uint32_t)(twin_p1 >> 32), (uint32_t)twin_p2, (uint32_t)(twin_p2 >> 32));
+        lds_st2(arr + kGD + 1u, (uint32_t)twin_p3, (uint32_t)(twin_p3 >> 32));
         TSQ_TRACE(2, t);
         TSQ_DELAY(1);
         stage_publish(ctl, 2, t + 1u, lane);
@@ -381,10 +392,10 @@ __device__ __forceinline__ void stage_near(uint32_t n, lds_u8_t* lds, uint32_t l
     for (uint32_t t = 0; t < n_tiles; ++t, slot = slot + 1u == StageCfg::R ? 0u : slot + 1u) {
         if (!stage_wait_seen(ctl, 2, t + 1u, scanned_seen, 0)) break;
         volatile lds_u32_t* rec = recs + slot * StageCfg::REC_WORDS;
-        volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
-        const uint32_t tin_lo = arr[kATin * 64], tin_hi = arr[(kATin + 1) * 64];
-        const uint32_t tp1_lo = arr[kATp1 * 64], tp1_hi = arr[(kATp1 + 1) * 64];
-        const uint32_t tp2_lo = arr[kATp2 * 64], tp2_hi = arr[(kATp2 + 1) * 64];
+        volatile lds_u32_t* arr = rec + StageCfg::ARR + lane * 4u;
+        const u32x2_t gi = lds_ld2(arr + kGB + 2u);
+        const u32x4_t gc = lds_ld4(arr + kGC);
+        const uint32_t tin_lo = gi.x, tin_hi = gi.y, tp1_lo = gc.x, tp1_hi = gc.y, tp2_lo = gc.z, tp2_hi = gc.w;
         const bool in0 = (tin_lo | tin_hi) != 0u, in1 = (tp1_lo | tp1_hi) != 0u, in2 = (tp2_lo | tp2_hi) != 0u;
         uint32_t word = 0;
         if (__ballot(in0 || in1 || in2) != 0ull) {
@@ -398,7 +409,7 @@ __device__ __forceinline__ void stage_near(uint32_t n, lds_u8_t* lds, uint32_t l
             // (with extensions a prefix of 16 may go on: WALK takes the long way round for those)
             if ((in0 || in1 || in2) && !(EXT && k >= 16u)) word = 0x8000u | (back << 12) | (q << 6) | k;
         }
-        arr[kAOwn * 64] = word;
+        arr[kGB + 1u] = word;
         TSQ_DELAY(2);
         stage_publish(ctl, kCtlNear, t + 1u, lane);
     }
@@ -429,14 +440,17 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         if (!stage_wait_seen(ctl, 2, t + 1u, scanned_seen, 2)) break;
         TSQ_TRACE(3, t);
         volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
-        volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
-        const uint32_t h = arr[kAH * 64];
+        volatile lds_u32_t* arr = rec + StageCfg::ARR + lane * 4u;
+        const u32x4_t gd = lds_ld4(arr + kGD);
         const u32x4_t wv = *(volatile lds_u32x4_t*)(rec + StageCfg::W16 + lane * 4u);
+        const u32x2_t gi = lds_ld2(arr + kGB + 2u);
+        const u32x4_t gc = lds_ld4(arr + kGC);
+        const uint32_t h = gd.x;
         const uint4 w16 = make_uint4(wv.x, wv.y, wv.z, wv.w);
-        const uint64_t twin_in = (uint64_t)arr[kATin * 64] | ((uint64_t)arr[(kATin + 1) * 64] << 32);
-        const uint64_t twin_p1 = (uint64_t)arr[kATp1 * 64] | ((uint64_t)arr[(kATp1 + 1) * 64] << 32);
-        const uint32_t tp2_any = arr[kATp2 * 64] | arr[(kATp2 + 1) * 64];
-        const uint32_t tp3_lo = arr[kATp3 * 64], tp3_hi = arr[(kATp3 + 1) * 64];
+        const uint64_t twin_in = (uint64_t)gi.x | ((uint64_t)gi.y << 32);
+        const uint64_t twin_p1 = (uint64_t)gc.x | ((uint64_t)gc.y << 32);
+        const uint32_t tp2_any = gc.z | gc.w;
+        const uint32_t tp3_lo = gd.y, tp3_hi = gd.z;
         MREG_END(10);
         MREG_BEGIN(12);
         // ---- the table holds the visits of tiles <= t-4 (the COMMIT wave has published them: its stores are complete and the
@@ -537,8 +551,8 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         // (tsq_encode.cpp:100), whatever the pair origin: such a lane is a plain "no match", not a hazard
         const bool hard_l = (eq4 && !far_enough && dist >= 4u && !neart) || tail;
         const bool twin_l = (twin_in | twin_p1) != 0ull || tp2_any != 0u;
-        arr[kASpan * 64] = span_nat | (hard_l ? 0x100u : 0u) | (twin_l ? 0x200u : 0u) | (certain ? 0x400u : 0u) | (neart ? 0x800u : 0u) | (k0 << 16);
-        arr[kALane * 64] = cand0 | (nib << 24);
+        lds_st2(arr + kGA, span_nat | (hard_l ? 0x100u : 0u) | (twin_l ? 0x200u : 0u) | (certain ? 0x400u : 0u) | (neart ? 0x800u : 0u) | (k0 << 16),
+                cand0 | (nib << 24));
 #ifdef TSQ_STATS
         if (t >= 3u) { st_[24] += (uint32_t)((uint32_t)__builtin_amdgcn_s_memtime() - uniform(ctl[40u + ((t - 3u) & 7u)])); st_[25] += 1; }
 #endif
@@ -571,9 +585,10 @@ __device__ __forceinline__ void stage_commit(uint32_t n, uint16_t* table, lds_u8
     for (uint32_t t = 0; t < n_tiles; ++t) {
         if (!stage_wait(ctl, 5, t + 1u, 3)) break;
         volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
-        volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
-        const uint32_t h = arr[kAH * 64];
-        const uint32_t tin_lo = arr[kATin * 64], tin_hi = arr[(kATin + 1) * 64];
+        volatile lds_u32_t* arr = rec + StageCfg::ARR + lane * 4u;
+        const uint32_t h = arr[kGD];
+        const u32x2_t gi = lds_ld2(arr + kGB + 2u);
+        const uint32_t tin_lo = gi.x, tin_hi = gi.y;
         const uint64_t tw = (uint64_t)uniform(rec[0]) | ((uint64_t)uniform(rec[1]) << 32);   // lanes with an earlier twin inside the tile
         lds_u32_t* visw = (lds_u32_t*)(rec + 2u);
         const uint64_t vis = (uint64_t)uniform(__hip_atomic_load(&visw[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) |
@@ -617,7 +632,7 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
     uint32_t scanned_seen = 0, parsed_seen = 0, near_seen = 0;
     for (uint32_t t = parity; t < n_tiles; t += 2u) {
         volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
-        volatile lds_u32_t* arr = rec + StageCfg::ARR + lane;
+        volatile lds_u32_t* arr = rec + StageCfg::ARR + lane * 4u;
         // ---- late classification of lanes whose only twins are in tile t-2.  By now the parser has (almost always)
         //      finished that tile, so which of those twins were visited is known: the most recent visited one IS the
         //      candidate (tsq_encode.cpp:76-79), 65..191 bytes back.  Such a lane becomes an ordinary certain lane and
@@ -627,8 +642,10 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
         bool fix = false, clear_tp2 = false;
         if (TSQ_LATE_FIX && t >= 2u) {
             if (!stage_wait_seen(ctl, 2, t + 1u, scanned_seen, 6)) break;
-            const uint32_t tp2_lo = arr[kATp2 * 64], tp2_hi = arr[(kATp2 + 1) * 64];
-            const uint32_t nearer = arr[kATin * 64] | arr[(kATin + 1) * 64] | arr[kATp1 * 64] | arr[(kATp1 + 1) * 64];
+            const u32x4_t gc = lds_ld4(arr + kGC);
+            const u32x2_t gi = lds_ld2(arr + kGB + 2u);
+            const uint32_t tp2_lo = gc.z, tp2_hi = gc.w;
+            const uint32_t nearer = gi.x | gi.y | gc.x | gc.y;
             const uint32_t p = (t << 6) + lane;
             const bool only2 = (tp2_lo | tp2_hi) != 0u && nearer == 0u && p < tail_from;
             if (__ballot(only2) != 0ull) {
@@ -660,16 +677,17 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
         uint32_t sw;
         {
             const uint32_t seen_v = ((volatile lds_u32_t*)ctl)[parity ? kCtlMatchedOdd : 3u];
-            sw = arr[kASpan * 64];
+            sw = arr[kGA];
             asm volatile("" ::: "memory");
             if (uniform(seen_v) < t + 1u) {
                 if (!stage_wait_tight(ctl, parity ? kCtlMatchedOdd : 3u, t + 1u, 6)) break;
-                sw = arr[kASpan * 64];
+                sw = arr[kGA];
             }
         }
         TSQ_TRACE(11, t);
-        if (fix) { sw = fix_sw; arr[kASpan * 64] = fix_sw; arr[kALane * 64] = fix_lw; }
-        if (clear_tp2) { sw |= 0x1000u; arr[kASpan * 64] = sw; }      // (SCAN's masks stay as they are: later tiles inherit from them)
+        if (clear_tp2) fix_sw |= 0x1000u;
+        if (fix) { sw = fix_sw; lds_st2(arr + kGA, fix_sw, fix_lw); }
+        else if (clear_tp2) { sw |= 0x1000u; arr[kGA] = sw; }        // (SCAN's masks stay as they are: later tiles inherit from them)
         // the whole orbit of every lane, by pointer doubling: `nx` = where the orbit started at this lane halts
         // (lane, or position past the tile: 7 bits | halted: bit 7), `orb` = the lanes it visits before that.
         // A hop halts when it lands on a hard lane or past the tile.  Twin lanes do not halt: the parser takes
@@ -689,9 +707,8 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
         }
         // (WALK also reads NEAR's word of the tile: NEAR runs tiles ahead, this wait is satisfied by what was read long ago)
         if (!stage_wait_seen(ctl, kCtlNear, t + 1u, near_seen, 6)) break;
-        arr[kANx * 64] = nx;
-        arr[kAOrb * 64] = (uint32_t)orb;
-        arr[(kAOrb + 1) * 64] = (uint32_t)(orb >> 32);
+        lds_st2(arr + kGA + 2u, nx, (uint32_t)orb);
+        arr[kGB] = (uint32_t)(orb >> 32);
 #ifdef TSQ_STATS
         if (t >= 3u) { st_[24] += (uint32_t)((uint32_t)__builtin_amdgcn_s_memtime() - uniform(ctl[40u + ((t - 3u) & 7u)])); st_[25] += 1; }
 #endif
@@ -811,17 +828,13 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
             REG_BEGIN(1);
             // (the serial stage polls without sleeping: a wake-up from s_sleep costs it up to 64 cycles per hand-off)
             const uint32_t orbit_word = (t & 1u) ? kCtlOrbitOdd : 4u;
-            volatile lds_u32_t* arr = recs + rec_slot * StageCfg::REC_WORDS + StageCfg::ARR + lane;
+            volatile lds_u32_t* arr = recs + rec_slot * StageCfg::REC_WORDS + StageCfg::ARR + lane * 4u;
             uint32_t spanword, lane_word, nx, orb_lo, orb_hi, tin_lo, tin_hi, tp1_lo, tp1_hi, tp2r_lo, tp2r_hi, nearw;
             auto load_record = [&]() {
-                spanword = arr[kASpan * 64];
-                lane_word = arr[kALane * 64];
-                nx = arr[kANx * 64];
-                orb_lo = arr[kAOrb * 64]; orb_hi = arr[(kAOrb + 1) * 64];
-                tin_lo = arr[kATin * 64]; tin_hi = arr[(kATin + 1) * 64];
-                tp1_lo = arr[kATp1 * 64]; tp1_hi = arr[(kATp1 + 1) * 64];
-                tp2r_lo = arr[kATp2 * 64]; tp2r_hi = arr[(kATp2 + 1) * 64];
-                nearw = arr[kAOwn * 64];
+                const u32x4_t ga = lds_ld4(arr + kGA), gb = lds_ld4(arr + kGB), gc = lds_ld4(arr + kGC);      // three LDS instructions
+                spanword = ga.x; lane_word = ga.y; nx = ga.z; orb_lo = ga.w;
+                orb_hi = gb.x; nearw = gb.y; tin_lo = gb.z; tin_hi = gb.w;
+                tp1_lo = gc.x; tp1_hi = gc.y; tp2r_lo = gc.z; tp2r_hi = gc.w;
             };
             // The counter and the record's words are requested together: the LDS serves a wavefront's requests in order, so when the
             // counter (asked for first) says the record is there, the words that came back behind it are the record's; only when it is
@@ -975,8 +988,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                     const uint32_t m = EXT ? length_nibble(need) : need - 1u;
                     const uint32_t sp = s_sel(is_m, EXT ? nibble_span(m) : need, 1u);
                     if (lane == L) {
-                        arr[kASpan * 64] = (spanword & ~0x4FFu) | sp | (is_m << 10);
-                        arr[kALane * 64] = cand | (m << 24);
+                        lds_st2(arr + kGA, (spanword & ~0x4FFu) | sp | (is_m << 10), cand | (m << 24));
                     }
                     v = i + sp;
                     last_m = s_sel(is_m, i, last_m);
@@ -1180,9 +1192,9 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
             if (new_tile) { flush_pending(); qmask = 0; }
             base = ev_base;
             const uint32_t t = base >> 6;
-            volatile lds_u32_t* arr = recs + (t % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::ARR + lane;
-            const uint32_t spanword = arr[kASpan * 64];
-            const uint32_t fresh_lw = arr[kALane * 64];
+            volatile lds_u32_t* arr = recs + (t % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::ARR + lane * 4u;
+            const u32x2_t ga = lds_ld2(arr + kGA);
+            const uint32_t spanword = ga.x, fresh_lw = ga.y;
             lw = ((qmask >> lane) & 1ull) ? lw : fresh_lw;            // (a lane a query decided keeps the candidate ACCOUNT gave it)
             span_nat = spanword & 0xFFu;
             certain_m = __ballot((spanword & 0x400u) != 0u);
