@@ -8,13 +8,17 @@
 // TSQ_AMD_DEVICES (default: the current device), so with 8 devices consecutive batches go to
 // consecutive GPUs and the host gathers the compressed pieces in block order -- the analogue
 // of block i -> worker i % num_cores (tsq_threads.cpp:71,463) and of the ordered writer
-// (tsq_threads.cpp:192-275, 604-676).  While lane A computes, the scheduler thread drains the
-// oldest lane (D2H + append + progress callbacks) and stages the next batch.
+// (tsq_threads.cpp:192-275, 604-676).  Three kinds of threads per context, as in the reference (reader / workers / writer,
+// tsq_threads.cpp:52-275): one FEEDER per listed device issues that device's batches -- file read into pinned staging (parallel
+// pread), copy to the device, kernel launches -- so that the devices' feeds do not queue behind each other and a file read overlaps
+// the previous batch's kernels and copy back; the scheduler thread cuts the job and, for compression, drains the oldest lane
+// (D2H + append + progress callbacks); decompression has its own drainer thread.
 #include "tsq_internal.h"
 #include "tsq_common.cuh"
 
 #include "../../include/turbosqueeze.h"
 
+#include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/uio.h>
 #include <unistd.h>
@@ -27,6 +31,7 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -75,8 +80,45 @@ struct Marks {
     const bool on = getenv("TSQ_AMD_DEBUG") != nullptr;
     double t0 = now();
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-    void at(const char* what) { if (on) { double t = now(); fprintf(stderr, "turbosqueeze_amd: %8.2f ms  %s\n", (t - t0) * 1e3, what); } }
+    void at(const char* what, int feeder = -1) {
+        if (!on) return;
+        const double t = now();
+        if (feeder < 0) fprintf(stderr, "turbosqueeze_amd: %8.2f ms  %s\n", (t - t0) * 1e3, what);
+        else fprintf(stderr, "turbosqueeze_amd: %8.2f ms  [feeder %d] %s\n", (t - t0) * 1e3, feeder, what);
+    }
 };
+
+// Positional file I/O in a few threads: one thread moves 2-3 GB/s in and out of the page cache, a batch is hundreds of megabytes.
+size_t io_threads_for(size_t n)
+{
+    if (n < (size_t(8) << 20)) return 1;
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t k = hw >= 8 ? 2 : 1;            // (measured on the 16-CPU-quota box: 2 threads 0.72 / 0.85 s per 4 GiB, 4: 0.83 / 0.97, 8: 0.95 / 1.36 -- the quota throttles)
+    if (const char* e = getenv("TSQ_AMD_IO_THREADS")) { long v = atol(e); if (v >= 1 && v <= 64) k = (size_t)v; }
+    return k;
+}
+template <class F>   // F(fd, ptr, len, offset) -> ssize_t (pread / pwrite)
+bool io_par(F op, int fd, uint8_t* p, size_t n, size_t at)
+{
+    auto all = [&](uint8_t* q, size_t len, size_t off) {
+        size_t done = 0;
+        while (done < len) { ssize_t r = op(fd, q + done, len - done, (off_t)(off + done)); if (r <= 0) return false; done += (size_t)r; }
+        return true;
+    };
+    const size_t k = io_threads_for(n);
+    if (k <= 1) return all(p, n, at);
+    const size_t per = ((n / k) + 4095) & ~size_t(4095);
+    std::atomic<bool> good{true};
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < k; ++i) {
+        const size_t a = per * i;
+        if (a >= n) break;
+        const size_t len = n - a < per ? n - a : per;
+        th.emplace_back([&, a, len] { if (!all(p + a, len, at + a)) good = false; });
+    }
+    for (auto& t : th) t.join();
+    return good;
+}
 
 void complain_once(const char* what)
 {
@@ -89,8 +131,23 @@ void complain_once(const char* what)
 // in one by one costs more than the copy.  A few threads touch them while the kernels run.
 struct Prefault {
     std::vector<std::thread> th;
-    void start(uint8_t* p, size_t n) {
+    // A mapped file (fd >= 0): its pages are allocated by fallocate, 64 MiB at a time from the start (one call allocates at several
+    // times the rate page faults or write() do on one file: tools/streamed_files.sh), ahead of the batches that land in it.
+    std::atomic<size_t> allocated{0};
+    void start(uint8_t* p, size_t n, int fd = -1) {
         if (!p || n < (size_t(64) << 20)) return;
+        if (fd >= 0) {
+            allocated = 0;
+            th.emplace_back([this, fd, n] {
+                const size_t step = size_t(64) << 20;
+                for (size_t a = 0; a < n; a += step) {
+                    const size_t len = n - a < step ? n - a : step;
+                    (void)posix_fallocate(fd, (off_t)a, (off_t)len);       // (on failure the pages simply come from the faults below)
+                    allocated = a + len;
+                }
+            });
+            return;
+        }
         {   // transparent huge pages where the system allows them on request: 2 MiB per fault instead of 4 KiB
             uintptr_t a0 = (reinterpret_cast<uintptr_t>(p) + 4095) & ~uintptr_t(4095);
             (void)madvise(reinterpret_cast<void*>(a0), (n - 4096) & ~size_t(4095), MADV_HUGEPAGE);
@@ -122,42 +179,22 @@ struct Source {
             size = (size_t)s;
             // Files that fit in memory are read whole, by several threads, and then go down the memory path (device-filling
             // batches, direct copies); larger ones stream through pinned staging in smaller batches.
-            if (size > 0 && size <= env_size("TSQ_AMD_FILE_INMEM_MAX", size_t(16) << 30)) {
+            if (size > 0 && size <= env_size("TSQ_AMD_FILE_INMEM_MAX", size_t(64) << 20)) {
                 loaded = static_cast<uint8_t*>(malloc(size + kHalo));
                 if (loaded) {
-                    const int fd = fileno(f);
-                    unsigned hw = std::thread::hardware_concurrency();
-                    const unsigned k = size < (size_t(64) << 20) ? 1 : hw >= 32 ? 16 : hw >= 8 ? 4 : 1;
-                    const size_t per = ((size / k) + 4095) & ~size_t(4095);
-                    std::atomic<bool> good{true};
-                    std::vector<std::thread> th;
-                    for (unsigned i = 0; i < k; ++i) {
-                        const size_t a = per * i;
-                        if (a >= size) break;
-                        const size_t len = size - a < per ? size - a : per;
-                        th.emplace_back([this, fd, a, len, &good] {
-                            size_t done = 0;
-                            while (done < len) {
-                                ssize_t r = pread(fd, loaded + a + done, len - done, (off_t)(a + done));
-                                if (r <= 0) { good = false; return; }
-                                done += (size_t)r;
-                            }
-                        });
-                    }
-                    for (auto& t : th) t.join();
-                    if (good) mem = loaded; else { free(loaded); loaded = nullptr; }
+                    if (io_par(pread, fileno(f), loaded, size, 0)) mem = loaded; else { free(loaded); loaded = nullptr; }
                 }
             }
         } else { mem = in; size = szin; }
         return true;
     }
-    // read [at, at+len) into dst; returns bytes obtained
+    // read [at, at+len) into dst; returns bytes obtained.  Positional reads (pread, several threads for a large piece): safe from
+    // any thread, the scheduler's frame walk and a feeder's batch read do not disturb each other.
     size_t read_at(size_t at, size_t len, uint8_t* dst) {
         if (at >= size) return 0;
         if (len > size - at) len = size - at;
         if (mem) { memcpy(dst, mem + at, len); return len; }
-        if (fseek(f, (long)at, SEEK_SET) != 0) return 0;
-        return fread(dst, 1, len, f);
+        return io_par(pread, fileno(f), dst, len, at) ? len : 0;
     }
     ~Source() { if (own && f) fclose(f); free(loaded); }
 };
@@ -165,16 +202,35 @@ struct Source {
 struct Sink {
     uint8_t* mem = nullptr; size_t cap = 0, at = 0; FILE* f = nullptr; bool own = false; bool failed = false;
     bool open_file(const char* path) { f = fopen(path, "wb"); own = true; return f != nullptr; }
-    // file outputs whose bound fits in memory: collect like a memory sink, write once at the end
+    // small file outputs: collected like a memory sink, written once at the end.  Larger ones are MAPPED at their bound and
+    // filled like memory too (pinned staging + a CPU copy into the page cache, whose pages a background fallocate provides ahead of
+    // the batches; the file is cut to its length at the end): write() calls on one file take the inode lock one after the other and
+    // top out near 3-6 GB/s however many threads make them (tools/streamed_files.sh).
     bool open_file_buffered(const char* path, size_t capacity) {
         if (!open_file(path)) return false;
-        if (capacity <= env_size("TSQ_AMD_FILE_INMEM_MAX", size_t(16) << 30)) {
+        if (capacity <= env_size("TSQ_AMD_FILE_MAP_MIN", size_t(64) << 20)) {
             mem = static_cast<uint8_t*>(malloc(capacity ? capacity : 1));
             if (mem) { cap = capacity; pending_file = f; f = nullptr; }
+        } else if (!getenv("TSQ_AMD_FILE_NO_MMAP")) {
+            fclose(f); f = nullptr;
+            map_fd = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
+            if (map_fd < 0) return false;
+            if (ftruncate(map_fd, (off_t)capacity) == 0) {
+                void* p = mmap(nullptr, capacity, PROT_READ | PROT_WRITE, MAP_SHARED, map_fd, 0);
+                if (p != MAP_FAILED) { mem = static_cast<uint8_t*>(p); cap = capacity; mapped = true; return true; }
+            }
+            ::close(map_fd); map_fd = -1;
+            return open_file(path);                                      // (a file system without mmap: positional writes)
         }
         return true;
     }
     bool finish() {
+        if (mapped) {
+            (void)munmap(mem, cap); mem = nullptr; mapped = false;
+            if (ftruncate(map_fd, (off_t)at) != 0) failed = true;
+            ::close(map_fd); map_fd = -1;
+            return !failed;
+        }
         if (pending_file) {
             if (!failed && fwrite(mem, 1, at, pending_file) != at) failed = true;
             f = pending_file; pending_file = nullptr;
@@ -183,16 +239,34 @@ struct Sink {
         return !failed;
     }
     FILE* pending_file = nullptr;
+    int map_fd = -1; bool mapped = false;
     bool open_mem(size_t capacity) { mem = static_cast<uint8_t*>(malloc(capacity ? capacity : 1)); cap = capacity; return mem != nullptr; }
     // where the next n bytes will land (memory sinks): the device copies there directly
     uint8_t* claim(size_t n) { if (f || at + n > cap) { failed = true; return nullptr; } uint8_t* p = mem + at; at += n; return p; }
     void write(const uint8_t* p, size_t n) {
-        if (f) { if (fwrite(p, 1, n, f) != n) failed = true; }
-        else if (at + n <= cap) memcpy(mem + at, p, n);
+        if (f) {      // streamed file output: positional writes at the running offset, several threads for a large piece
+            if (at == 0) (void)fflush(f);
+            if (!io_par([](int fd, uint8_t* q, size_t len, off_t off) { return pwrite(fd, q, len, off); }, fileno(f), const_cast<uint8_t*>(p), n, at)) failed = true;
+        }
+        else if (at + n <= cap) {
+            const size_t k = mapped ? io_threads_for(n) : 1;      // (a mapped file: the copy takes the pages' minor faults, in a few threads)
+            if (k <= 1) memcpy(mem + at, p, n);
+            else {
+                const size_t per = ((n / k) + 4095) & ~size_t(4095);
+                std::vector<std::thread> th;
+                for (size_t i = 0; i < k && per * i < n; ++i)
+                    th.emplace_back([this, p, n, per, i] { const size_t a = per * i; memcpy(mem + at + a, p + a, n - a < per ? n - a : per); });
+                for (auto& t : th) t.join();
+            }
+        }
         else failed = true;
         at += n;
     }
-    ~Sink() { if (pending_file) { fclose(pending_file); free(mem); } else if (own && f) fclose(f); }
+    ~Sink() {
+        if (mapped) { (void)munmap(mem, cap); ::close(map_fd); }
+        else if (pending_file) { fclose(pending_file); free(mem); }
+        else if (own && f) fclose(f);
+    }
 };
 
 // ---- one pipeline lane ----
@@ -269,6 +343,43 @@ struct Job {
 
 struct InFlight { size_t lane; uint32_t first_block, n_blocks; size_t out_bytes; };
 
+// One thread per listed device: it issues that device's batches (file read, copy to the device, launches).  A copy from pageable
+// memory holds the issuing thread for its whole duration; with one issuing thread for all devices the feeds would queue behind each
+// other (the reference gives every worker its own thread, tsq_threads.cpp:137-189).
+struct Feeder {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    bool quit = false;
+    void start() {
+        th = std::thread([this] {
+            for (;;) {
+                std::function<void()> fn;
+                {
+                    std::unique_lock<std::mutex> g(m);
+                    cv.wait(g, [this] { return quit || !q.empty(); });
+                    if (q.empty()) return;
+                    fn = std::move(q.front());
+                    q.pop_front();
+                }
+                fn();
+            }
+        });
+    }
+    void push(std::function<void()> fn) { { std::lock_guard<std::mutex> g(m); q.push_back(std::move(fn)); } cv.notify_one(); }
+    void stop() { { std::lock_guard<std::mutex> g(m); quit = true; } cv.notify_all(); if (th.joinable()) th.join(); }
+};
+// "the lane's batch has been issued" (1) or could not be (2), set by the feeder, awaited by whoever drains the lane
+struct Issued {
+    std::mutex m;
+    std::condition_variable cv;
+    int state = 0;
+    void reset() { std::lock_guard<std::mutex> g(m); state = 0; }
+    void set(bool ok) { { std::lock_guard<std::mutex> g(m); state = ok ? 1 : 2; } cv.notify_all(); }
+    bool wait() { std::unique_lock<std::mutex> g(m); cv.wait(g, [this] { return state != 0; }); return state == 1; }
+};
+
 class Scheduler {
 public:
     explicit Scheduler(bool compress, bool verbose) : compress_(compress), verbose_(verbose) {}
@@ -281,7 +392,9 @@ public:
             Lane l;
             if (!l.init(devs[k % devs.size()])) { l.destroy(); for (auto& x : lanes_) x.destroy(); lanes_.clear(); return false; }
             lanes_.push_back(l);
+            issued_.emplace_back(new Issued());
         }
+        for (size_t d = 0; d < devs.size(); ++d) { feeders_.emplace_back(new Feeder()); feeders_.back()->start(); }
         // one batch should fill the device: a block is one workgroup for its whole (serial) parse, and two of them share a CU
         // (the encoder's lean layout) at 1.5x the throughput of one
         batch_blocks_ = (uint32_t)env_size("TSQ_AMD_BATCH_BLOCKS", 512);
@@ -309,6 +422,8 @@ public:
             cv_.notify_all();
         }
         if (thread_.joinable()) thread_.join();
+        for (auto& f : feeders_) f->stop();
+        feeders_.clear();
         for (auto& l : lanes_) l.destroy();
         lanes_.clear();
     }
@@ -336,7 +451,12 @@ private:
     }
     // Blocks per device-to-host piece: progress is reported per block as its bytes land; a piece of a few blocks keeps
     // the copies large enough for the DMA engines (one 4 MiB block per copy costs about a third of the bandwidth).
-    static uint32_t progress_piece(uint32_t n_blocks) { return n_blocks >= 64 ? 8u : n_blocks >= 8 ? 2u : 1u; }
+    // (through staging -- a file on the output side -- the pieces are larger: each is copied to pinned memory while the one before
+    //  it is written, and a piece's write wants tens of megabytes to be worth its threads)
+    static uint32_t progress_piece(uint32_t n_blocks, bool staged = false) {
+        if (staged && n_blocks >= 32) return n_blocks / 4;
+        return n_blocks >= 64 ? 8u : n_blocks >= 8 ? 2u : 1u;
+    }
 
     void loop() {
         for (;;) {
@@ -377,32 +497,46 @@ private:
         bool ok = true;
         std::deque<InFlight> fly;
         uint32_t done_blocks = 0;
-        const bool stage_in = src.mem == nullptr, stage_out = sink.mem == nullptr;
+        // (a mapped output file takes its bytes through pinned staging and a CPU copy: a device copy straight into file-backed pages
+        //  runs at a fraction of the link's rate)
+        const bool stage_in = src.mem == nullptr, stage_out = sink.mem == nullptr || sink.mapped;
         const uint32_t batch = job_batch(nb, stage_in || stage_out);
         Marks mk; mk.at("compress: buffers opened");
         Prefault touch;
-        if (!stage_out) touch.start(sink.mem, sink.cap < total ? sink.cap : total);   // (the bound is 1.25x; text lands at 0.6x)
+        if (sink.mapped) touch.start(sink.mem, total - total / 4, sink.map_fd);       // (the bound is 1.25x; text lands at 0.6x)
+        else if (!stage_out) touch.start(sink.mem, sink.cap < total ? sink.cap : total);
         auto drain_one = [&]() {
             InFlight f = fly.front(); fly.pop_front();
             Lane& l = lanes_[f.lane];
+            if (!issued_[f.lane]->wait()) { ok = false; return; }     // the lane's feeder has issued the batch (or failed to)
             (void)hipSetDevice(l.dev->device);
             if (hipEventSynchronize(l.ev) != hipSuccess || *l.h_status != 0) { ok = false; return; }
             size_t sz = (size_t)*l.h_size;                            // batch container: 16-byte header + frames
             mk.at("compress: kernels done");
             if (sz < 16 || sz > l.out_cap) { ok = false; return; }
+            // (a mapped file is populated from its start while the batches land: nothing to wait for; a malloc'ed buffer is touched in
+            //  one share per thread and must be complete)
             if (!stage_out) { touch.join(); mk.at("compress: output pages touched"); }
             // The frames come back in pieces of a few blocks, in block order, and every block reports progress as soon as
             // its bytes have landed (tsq_threads.cpp:226-254: the writer emits a frame, then calls progress_cb).
             const uint64_t* fat = l.h_frame_at;                       // frame offsets inside the batch container
-            const uint32_t piece = progress_piece(f.n_blocks);
+            const uint32_t piece = progress_piece(f.n_blocks, stage_out);
+            // (through staging the next piece is copied to pinned memory while this one is written)
+            auto fetch = [&](uint32_t p0) -> bool {
+                const uint32_t p1 = p0 + piece < f.n_blocks ? p0 + piece : f.n_blocks;
+                const size_t from = (size_t)fat[p0], len = (size_t)fat[p1] - from;
+                if (from < 16 || from + len > sz) return false;
+                return hipMemcpyAsync(l.h_out + from, l.d_out + from, len, hipMemcpyDeviceToHost, l.dev->stream) == hipSuccess;
+            };
+            if (stage_out && !fetch(0)) { ok = false; return; }
             for (uint32_t p0 = 0; p0 < f.n_blocks && ok; p0 += piece) {
                 const uint32_t p1 = p0 + piece < f.n_blocks ? p0 + piece : f.n_blocks;
                 const size_t from = (size_t)fat[p0], len = (size_t)fat[p1] - from;
                 if (from < 16 || from + len > sz) { ok = false; return; }
                 if (stage_out) {
-                    if (hipMemcpyAsync(l.h_out, l.d_out + from, len, hipMemcpyDeviceToHost, l.dev->stream) != hipSuccess ||
-                        hipStreamSynchronize(l.dev->stream) != hipSuccess) { ok = false; return; }
-                    sink.write(l.h_out, len);
+                    if (hipStreamSynchronize(l.dev->stream) != hipSuccess) { ok = false; return; }
+                    if (p1 < f.n_blocks && !fetch(p1)) { ok = false; return; }
+                    sink.write(l.h_out + from, len);
                 } else {
                     uint8_t* dst = sink.claim(len);                   // frames land in the caller's buffer directly
                     if (!dst || hipMemcpyAsync(dst, l.d_out + from, len, hipMemcpyDeviceToHost, l.dev->stream) != hipSuccess ||
@@ -426,26 +560,38 @@ private:
             const size_t want = (size_t)bn * kBlockSize;
             const size_t n = total - at < want ? total - at : want;
             if (!l.reserve(want + kHalo, tsqa_container_bound(want), bn, stage_in, stage_out)) { ok = false; break; }
-            (void)hipSetDevice(l.dev->device);
-            hipStream_t s = l.dev->stream;
-            // the batch plus the first bytes of the next one: block k's look-ahead reads block k+1
-            size_t got = total - at < n + kHalo ? total - at : n + kHalo;
-            if (stage_in) {
-                got = src.read_at(at, n + kHalo, l.h_in);
-                if (got < n) { ok = false; break; }
-                if (hipMemcpyAsync(l.d_in, l.h_in, got, hipMemcpyHostToDevice, s) != hipSuccess) { ok = false; break; }
-            } else if (hipMemcpyAsync(l.d_in, src.mem + at, got, hipMemcpyHostToDevice, s) != hipSuccess) { ok = false; break; }
-            mk.at("compress: H2D issued");
-            if (hipMemsetAsync(l.dev->d_status, 0, sizeof(int32_t), s) != hipSuccess) { ok = false; break; }
-            if (l.dev->launch_encode(l.d_in, n, got, j.ext ? 1u : 0u, l.dev->d_status, s) != TSQA_OK) { ok = false; break; }
-            if (l.dev->launch_pack(n, j.ext ? 1u : 0u, l.d_out, l.out_cap, l.dev->d_size, l.dev->d_status, s) != TSQA_OK) { ok = false; break; }
-            (void)hipMemcpyAsync(l.h_size, l.dev->d_size, sizeof(uint64_t), hipMemcpyDeviceToHost, s);
-            (void)hipMemcpyAsync(l.h_frame_at, l.dev->frame_at, (bn + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s);
-            (void)hipMemcpyAsync(l.h_status, l.dev->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s);
-            if (hipEventRecord(l.ev, s) != hipSuccess) { ok = false; break; }
+            // the batch is issued by the lane's device feeder: read (file sources), copy to the device, kernels, result words
+            Issued* flag = issued_[lane_i].get();
+            flag->reset();
+            const int feeder = (int)(lane_i % feeders_.size());
+            const uint32_t ext = j.ext ? 1u : 0u;
+            feeders_[feeder]->push([&src, &mk, &l, flag, at, n, total, bn, stage_in, ext, feeder] {
+                bool good = true;
+                (void)hipSetDevice(l.dev->device);
+                hipStream_t s = l.dev->stream;
+                // the batch plus the first bytes of the next one: block k's look-ahead reads block k+1
+                size_t got = total - at < n + kHalo ? total - at : n + kHalo;
+                if (stage_in) {
+                    got = src.read_at(at, n + kHalo, l.h_in);
+                    mk.at("compress: batch read", feeder);
+                    good = got >= n && hipMemcpyAsync(l.d_in, l.h_in, got, hipMemcpyHostToDevice, s) == hipSuccess;
+                } else good = hipMemcpyAsync(l.d_in, src.mem + at, got, hipMemcpyHostToDevice, s) == hipSuccess;
+                mk.at("compress: H2D issued", feeder);
+                good = good && hipMemsetAsync(l.dev->d_status, 0, sizeof(int32_t), s) == hipSuccess;
+                good = good && l.dev->launch_encode(l.d_in, n, got, ext, l.dev->d_status, s) == TSQA_OK;
+                good = good && l.dev->launch_pack(n, ext, l.d_out, l.out_cap, l.dev->d_size, l.dev->d_status, s) == TSQA_OK;
+                if (good) {
+                    (void)hipMemcpyAsync(l.h_size, l.dev->d_size, sizeof(uint64_t), hipMemcpyDeviceToHost, s);
+                    (void)hipMemcpyAsync(l.h_frame_at, l.dev->frame_at, (bn + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s);
+                    (void)hipMemcpyAsync(l.h_status, l.dev->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+                    good = hipEventRecord(l.ev, s) == hipSuccess;
+                }
+                flag->set(good);
+            });
             fly.push_back({lane_i, b0, bn, 0});
         }
         while (ok && !fly.empty()) drain_one();
+        for (const InFlight& f : fly) (void)issued_[f.lane]->wait();    // (after a failure: no feeder may still be working on this job's buffers)
         for (auto& l : lanes_) { (void)hipSetDevice(l.dev->device); (void)hipStreamSynchronize(l.dev->stream); }
         touch.join();                                                 // nobody may still be touching the buffer when it is freed
         if (!sink.finish()) ok = false;
@@ -480,12 +626,13 @@ private:
         std::condition_variable fly_cv;
         bool fly_closed = false;
         uint32_t done_blocks = 0;
-        const bool stage_in = src.mem == nullptr, stage_out = sink.mem == nullptr;
+        const bool stage_in = src.mem == nullptr, stage_out = sink.mem == nullptr || sink.mapped;
         const uint32_t batch = job_batch(nb, stage_in || stage_out);
         Prefault touch;
         bool touching = false;
         auto drain = [&](const InFlight& f) {
             Lane& l = lanes_[f.lane];
+            if (!issued_[f.lane]->wait()) { ok = false; return; }     // the lane's feeder has issued the batch (or failed to)
             (void)hipSetDevice(l.dev->device);
             if (hipEventSynchronize(l.ev) != hipSuccess || *l.h_status != 0) { ok = false; return; }
             mk.at("decompress: kernels done");
@@ -495,15 +642,24 @@ private:
             uint8_t* dst = stage_out ? nullptr : sink.claim(f.out_bytes);
             if (!stage_out && !dst) { ok = false; return; }
             const FrameInfo* fr = l.h_frames;
-            const uint32_t piece = progress_piece(f.n_blocks);
+            const uint32_t piece = progress_piece(f.n_blocks, stage_out);
+            auto piece_span = [&](uint32_t p0, size_t& from, size_t& len) {
+                const uint32_t p1 = p0 + piece < f.n_blocks ? p0 + piece : f.n_blocks;
+                from = (size_t)fr[p0].out_at;
+                len = (size_t)(fr[p1 - 1].out_at + fr[p1 - 1].out_len) - from;
+            };
+            auto fetch = [&](uint32_t p0) {      // piece p0.. to its place in the caller's buffer, or in the pinned staging buffer
+                size_t from, len; piece_span(p0, from, len);
+                return hipMemcpyAsync(stage_out ? l.h_out + from : dst + from, l.d_out + from, len, hipMemcpyDeviceToHost, l.dev->stream) == hipSuccess;
+            };
+            if (!fetch(0)) { ok = false; return; }
             for (uint32_t p0 = 0; p0 < f.n_blocks && ok; p0 += piece) {
                 const uint32_t p1 = p0 + piece < f.n_blocks ? p0 + piece : f.n_blocks;
-                const size_t from = (size_t)fr[p0].out_at;
-                const size_t len = (size_t)(fr[p1 - 1].out_at + fr[p1 - 1].out_len) - from;
-                uint8_t* to = stage_out ? l.h_out : dst + from;
-                if (hipMemcpyAsync(to, l.d_out + from, len, hipMemcpyDeviceToHost, l.dev->stream) != hipSuccess ||
-                    hipStreamSynchronize(l.dev->stream) != hipSuccess) { ok = false; return; }
-                if (stage_out) sink.write(l.h_out, len);
+                size_t from, len; piece_span(p0, from, len);
+                if (hipStreamSynchronize(l.dev->stream) != hipSuccess) { ok = false; return; }
+                if (stage_out && p1 < f.n_blocks && !fetch(p1)) { ok = false; return; }      // the next piece comes in while this one is written
+                if (stage_out) sink.write(l.h_out + from, len);
+                else if (p1 < f.n_blocks && !fetch(p1)) { ok = false; return; }
                 for (uint32_t b = p0; b < p1; ++b) {
                     done_blocks++;
                     if (j.progress) j.progress(j.id, (double)done_blocks / (double)nb);
@@ -524,7 +680,7 @@ private:
                     if (fly.empty()) return;
                     f = fly.front();
                 }
-                if (ok) drain(f);
+                if (ok) drain(f); else (void)issued_[f.lane]->wait();  // (after a failure: the feeder must be done with the lane all the same)
                 {
                     std::lock_guard<std::mutex> g(fly_m);
                     fly.pop_front();                                  // only now may the lane be used again
@@ -562,10 +718,6 @@ private:
                 if (len < 3 || len > kSlotSize) { ok = false; break; }                         // tsq_threads.cpp:526-531
                 if (at + cur + 3 + len > src.size) { ok = false; break; }
                 if (cur + 3 + len > l.in_cap) break;
-                if (stage_in) {
-                    memcpy(l.h_in + cur, fh, 3);
-                    if (src.read_at(at + cur + 3, len, l.h_in + cur + 3) != len) { ok = false; break; }
-                }
                 uint32_t usize = (uint32_t)fh[3] | ((uint32_t)fh[4] << 8) | ((uint32_t)fh[5] << 16);
                 if (usize > kBlockSize || produced + out_bytes + usize > total) { ok = false; break; }
                 FrameInfo& fi = l.h_frames[bn];
@@ -575,17 +727,28 @@ private:
             if (!ok) break;
             if (bn == 0) { ok = false; break; }                        // truncated container
             // the result buffer is made resident only now that a first batch of frames has been found well formed
-            if (!stage_out && !touching) { touch.start(sink.mem, (size_t)total); touching = true; }
-            (void)hipSetDevice(l.dev->device);
-            hipStream_t s = l.dev->stream;
-            if (l.dev->reserve(bn, false, false) != TSQA_OK) { ok = false; break; }
-            if (hipMemcpyAsync(l.d_in, stage_in ? l.h_in : src.mem + at, cur, hipMemcpyHostToDevice, s) != hipSuccess) { ok = false; break; }
-            if (hipMemcpyAsync(l.dev->frames, l.h_frames, bn * sizeof(FrameInfo), hipMemcpyHostToDevice, s) != hipSuccess) { ok = false; break; }
-            if (hipMemsetAsync(l.dev->d_status, 0, sizeof(int32_t), s) != hipSuccess) { ok = false; break; }
-            if (l.dev->launch_decode(l.d_in, bn, l.d_out, l.dev->d_status, s) != TSQA_OK) { ok = false; break; }
-            (void)hipMemcpyAsync(l.h_status, l.dev->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s);
-            if (hipEventRecord(l.ev, s) != hipSuccess) { ok = false; break; }
-            mk.at("decompress: H2D + kernels issued");
+            if (!touching && (sink.mapped || !stage_out)) { touch.start(sink.mem, (size_t)total, sink.mapped ? sink.map_fd : -1); touching = true; }
+            // the batch's frames are one contiguous slice of the container: the lane's device feeder reads it (file sources), copies
+            // it to the device and launches the kernels
+            Issued* flag = issued_[lane_i].get();
+            flag->reset();
+            const int feeder = (int)(lane_i % feeders_.size());
+            feeders_[feeder]->push([&src, &mk, &l, flag, at, cur, bn, stage_in, feeder] {
+                (void)hipSetDevice(l.dev->device);
+                hipStream_t s = l.dev->stream;
+                bool good = l.dev->reserve(bn, false, false) == TSQA_OK;
+                if (good && stage_in) { good = src.read_at(at, cur, l.h_in) == cur; mk.at("decompress: batch read", feeder); }
+                good = good && hipMemcpyAsync(l.d_in, stage_in ? l.h_in : src.mem + at, cur, hipMemcpyHostToDevice, s) == hipSuccess;
+                good = good && hipMemcpyAsync(l.dev->frames, l.h_frames, bn * sizeof(FrameInfo), hipMemcpyHostToDevice, s) == hipSuccess;
+                good = good && hipMemsetAsync(l.dev->d_status, 0, sizeof(int32_t), s) == hipSuccess;
+                good = good && l.dev->launch_decode(l.d_in, bn, l.d_out, l.dev->d_status, s) == TSQA_OK;
+                if (good) {
+                    (void)hipMemcpyAsync(l.h_status, l.dev->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+                    good = hipEventRecord(l.ev, s) == hipSuccess;
+                }
+                mk.at("decompress: H2D + kernels issued", feeder);
+                flag->set(good);
+            });
             {
                 std::lock_guard<std::mutex> g(fly_m);
                 fly.push_back({lane_i, b0, bn, out_bytes});
@@ -606,7 +769,9 @@ private:
     }
 
     const bool compress_, verbose_;
-    std::vector<Lane> lanes_;
+    std::vector<Lane> lanes_;                          // lane k works on device k % n_devices_ and is fed by feeder k % n_devices_
+    std::vector<std::unique_ptr<Issued>> issued_;      // one per lane
+    std::vector<std::unique_ptr<Feeder>> feeders_;     // one per listed device
     uint32_t batch_blocks_ = 512, file_batch_blocks_ = 64, n_devices_ = 1;
     std::thread thread_;
     std::mutex m_;
