@@ -287,10 +287,11 @@ __device__ __forceinline__ void duo_parse(const uint8_t* __restrict__ in, uint32
                 rec[4] = (last_chunk ? DuoCfg::kLast : 0u) | (bad ? DuoCfg::kError : 0u);
                 rec[5] = cut_short ? W : W + C::S;                            // where the next record's window starts (for the COPY side's prefetch)
             }
-            // Every thread that stored part of the record makes its own stores visible at agent scope before the barrier: the
-            // workgroup-scope fence of __syncthreads() does not wait for global stores (no s_waitcnt vmcnt(0)), so without this
-            // another wave's record words could still be in flight when thread 0's flag becomes visible to the COPY workgroup.
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            // Every wavefront waits for ITS record stores to be acknowledged before the barrier (the workgroup-scope fence of
+            // __syncthreads() does not: no s_waitcnt vmcnt(0)), so that they are complete when thread 0 releases at agent scope (its
+            // release writes the L2 back once for the whole workgroup; an agent-scope release fence in every thread -- tried -- costs
+            // a write-back per wavefront and more than doubled the kernel's time).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) duo_store_release(flags, rec_no + 1u);            // ... and thread 0 publishes them
             if (bad) { if (tid == 0) atomicMax(status, kErrStream); return; }

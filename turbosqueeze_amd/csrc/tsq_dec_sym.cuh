@@ -54,14 +54,17 @@ struct SymCfg {
 struct SymLds {
     static constexpr uint32_t sbuf = 0;                                             // u8[S + SPAD + 16]
     static constexpr uint32_t j1 = sbuf + 16 * SymCfg::SWORDS;                      // u8[S]: next - offset
-    static constexpr uint32_t j2 = j1 + SymCfg::S;                                  // u16[S] each
-    static constexpr uint32_t j4 = j2 + 2 * SymCfg::S;
-    static constexpr uint32_t j8 = j4 + 2 * SymCfg::S;
-    static constexpr uint32_t j16 = j8 + 2 * SymCfg::S;
+    // u16[JN] each: next^2 .. next^16 of every offset; the entries S .. TERM hold TERM ("the chain has left the chunk": a fixed
+    // point), so that a look-up needs no range test
+    static constexpr uint32_t JN = (SymCfg::S + SymCfg::SPAD + 8u) & ~7u;
+    static constexpr uint32_t j2 = j1 + SymCfg::S;
+    static constexpr uint32_t j4 = j2 + 2 * JN;
+    static constexpr uint32_t j8 = j4 + 2 * JN;
+    static constexpr uint32_t j16 = j8 + 2 * JN;
     static constexpr uint32_t recw = j1;                                            // P5: u32[OUTC + 16] symbol records by first byte index, over j1 .. j16
     static constexpr uint32_t ent = j1;                                             // P5: u16[OUTC + 16] byte entries (once the records are read)
     static constexpr uint32_t plist = ent + 2 * (SymCfg::OUTC + 16);                // P5: u16[OUTC] per wavefront, the bytes that wait for a source
-    static constexpr uint32_t gstart = j16 + 2 * SymCfg::S;                         // u16[MAXG]
+    static constexpr uint32_t gstart = j16 + 2 * JN;                                // u16[MAXG]
     static constexpr uint32_t glen = gstart + 2 * SymCfg::MAXG;                     // u16[MAXG]
     static constexpr uint32_t gout = glen + 2 * SymCfg::MAXG;                       // u32[MAXG]
     static constexpr uint32_t pairs = gout + 4 * SymCfg::MAXG;                      // u32[4 * MAXG]: stream pos | out offset << 13 | 2 control bits << 30
@@ -253,15 +256,17 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
             for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t a = x[k] < slim ? x[k] : 0u; y[k] = a + j1[a]; }
 #pragma unroll
             for (uint32_t k = 0; k < C::PER; ++k) { x[k] = x[k] < slim ? y[k] : C::TERM; j2[tid + k * C::T] = (uint16_t)x[k]; }
+            // (the tables' tails: every offset from S to TERM is terminal)
+            if (tid <= C::SPAD) { j2[C::S + tid] = (uint16_t)C::TERM; j4[C::S + tid] = (uint16_t)C::TERM; j8[C::S + tid] = (uint16_t)C::TERM; j16[C::S + tid] = (uint16_t)C::TERM; }
             __syncthreads();
             const uint16_t* src = j2;
             uint16_t* const dsts[3] = {j4, j8, j16};
 #pragma unroll
             for (uint32_t d = 0; d < 3; ++d) {
 #pragma unroll
-                for (uint32_t k = 0; k < C::PER; ++k) y[k] = src[x[k] < slim ? x[k] : 0u];
+                for (uint32_t k = 0; k < C::PER; ++k) y[k] = src[x[k]];                       // x <= TERM, and src[TERM] == TERM
 #pragma unroll
-                for (uint32_t k = 0; k < C::PER; ++k) { x[k] = x[k] < slim ? y[k] : C::TERM; dsts[d][tid + k * C::T] = (uint16_t)x[k]; }
+                for (uint32_t k = 0; k < C::PER; ++k) { x[k] = y[k]; dsts[d][tid + k * C::T] = (uint16_t)x[k]; }
                 __syncthreads();
                 src = dsts[d];
             }
@@ -286,9 +291,9 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
             uint32_t x = C::TERM;
             if (tid < nsn * C::HOP) {
                 x = sn[tid >> 4];
-                if (tid & 8u) x = x < slim ? j8[x] : C::TERM;
-                if (tid & 4u) x = x < slim ? j4[x] : C::TERM;
-                if (tid & 2u) x = x < slim ? j2[x] : C::TERM;
+                if (tid & 8u) x = j8[x];
+                if (tid & 4u) x = j4[x];
+                if (tid & 2u) x = j2[x];
                 if (tid & 1u) x = x < slim ? (uint32_t)(x + j1[x]) : C::TERM;
             }
             uint32_t v = 0;
