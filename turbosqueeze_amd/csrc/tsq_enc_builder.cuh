@@ -126,28 +126,40 @@ __device__ __noinline__ EmitResult emit_batch(uint32_t rec, uint32_t cnt, uint32
 // kCtlEnd = 1 + the block's symbol count once the last symbol is recorded (0 before).
 enum : uint32_t { kCtlSyms = 7, kCtlBatches = 8, kCtlEnd = 9 };
 
-// BUILDER wave: items -> symbol records in the ring.
+// BUILDER: items -> symbol records in the ring.  An item carries the parse state at its entry, so items are independent: with
+// Cfg::DUAL_BUILDER two wavefronts take them alternately (wavefront `which` the items k = which mod 2).  Each publishes the next
+// item it will take (kCtlTail0 / kCtlTail1: ACCOUNT reuses a queue slot once both are past it), and the symbol count (kCtlSyms,
+// what EMIT waits for) in item order: item k's count goes out once the other wavefront is past item k-1.
+enum : uint32_t { kCtlTail0 = 1, kCtlTail1 = 38 };
 template <class Cfg>
-__device__ __forceinline__ void stream_builder(lds_u8_t* lds, uint32_t lane)
+__device__ __forceinline__ void stream_builder(lds_u8_t* lds, uint32_t lane, uint32_t which)
 {
     volatile lds_u32_t* queue = (volatile lds_u32_t*)(lds + Cfg::off_queue);
     volatile lds_u32_t* ring = (volatile lds_u32_t*)(lds + Cfg::off_ring);
     lds_u32_t* ctl = (lds_u32_t*)(lds + Cfg::off_ctl);
-    uint32_t tail = 0, batches_seen = 0, final_nsym = 0;
+    constexpr uint32_t STEP = Cfg::DUAL_BUILDER ? 2u : 1u;
+    uint32_t tail = which, batches_seen = 0, final_nsym = 0, other_seen = 0;
+    const uint32_t my_word = which ? kCtlTail1 : kCtlTail0, other_word = which ? kCtlTail0 : kCtlTail1;
 
 #ifdef TSQ_STATS
     unsigned long long st_[32] = {0};
     const unsigned long long begin_ = __builtin_amdgcn_s_memtime();
 #endif
     for (;;) {
-        if (__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == tail) {
+        if (__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= tail) {
 #ifdef TSQ_STATS
             const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
 #endif
-            while (__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == tail) { TSQ_SPIN(ctl); __builtin_amdgcn_s_sleep(1); }
+            bool ended = false;
+            while (__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= tail) {
+                // (the other wavefront took the end item: nothing more is coming)
+                if (Cfg::DUAL_BUILDER && uniform(__hip_atomic_load(&ctl[kCtlEnd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0u) { ended = true; break; }
+                TSQ_SPIN(ctl); __builtin_amdgcn_s_sleep(1);
+            }
 #ifdef TSQ_STATS
             st_[17] += __builtin_amdgcn_s_memtime() - w0_;
 #endif
+            if (ended) break;
         }
         volatile lds_u32_t* it = queue + (tail % Cfg::Q) * Cfg::ITEM_WORDS;
         TSQ_DELAY(8);
@@ -219,18 +231,36 @@ __device__ __forceinline__ void stream_builder(lds_u8_t* lds, uint32_t lane)
         // the item is consumed (its words are in registers, the records are on their way to the ring: the LDS executes a
         // wavefront's operations in order, so the counters below become visible after them)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        tail++;
+        // in item order: the other wavefront is past item tail - 1 (its records are in the ring and its count is out)
+        if (Cfg::DUAL_BUILDER && tail != 0u && other_seen < tail + 1u) {
+#ifdef TSQ_STATS
+            const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
+#endif
+            for (;;) {
+                other_seen = uniform(__hip_atomic_load(&ctl[other_word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (other_seen >= tail + 1u) break;
+                TSQ_SPIN(ctl);
+            }
+            asm volatile("" ::: "memory");
+#ifdef TSQ_STATS
+            st_[17] += __builtin_amdgcn_s_memtime() - w0_;
+#endif
+        }
+        tail += STEP;
         // (stores by every lane, and the loop exit on a plain uniform test: a `lane == 0` block that also tests `kind` in front of
         // the break was compiled into a divergent exit that dropped lanes 1..63 after the first item)
-        __hip_atomic_store(&ctl[1], tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (the count first: when the other wavefront sees this one past the item, the count it then stores comes later)
         __hip_atomic_store(&ctl[kCtlSyms], nsym_after, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&ctl[my_word], tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         final_nsym = nsym_after;
-        if (kind == kItemEnd) break;
+        if (kind == kItemEnd) {
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(&ctl[kCtlEnd], final_nsym + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            break;
+        }
     }
-    asm volatile("" ::: "memory");
-    __hip_atomic_store(&ctl[kCtlEnd], final_nsym + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifdef TSQ_STATS
-    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[17] = st_[17] + st_[19]; g_enc_stats[18] = __builtin_amdgcn_s_memtime() - begin_; g_enc_stats[37] = st_[19]; }
+    if (blockIdx.x == 0 && lane == 0 && which == 0u) { g_enc_stats[17] = st_[17] + st_[19]; g_enc_stats[18] = __builtin_amdgcn_s_memtime() - begin_; g_enc_stats[37] = st_[19]; }
 #endif
 }
 

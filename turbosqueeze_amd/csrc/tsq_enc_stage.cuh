@@ -35,6 +35,25 @@
 #ifndef TSQ_LATE_FIX
 #define TSQ_LATE_FIX 1
 #endif
+// Table lag LM: MATCH gathers tile t from a table that holds the visits of tiles <= t-LM-1 and patches in the visits of tile t-LM.
+// Late-fix lag LF: ORBIT settles the lanes whose only twins lie in tiles t-LM+1 .. t-LF once WALK has finished tile t-LF.
+// WALK looks after the twins of tiles t-LM+1 .. t.  LM = 3, LF = 2 was round 3's pipeline: the loops WALK(t-3) -> MATCH(t) -> ORBIT(t) ->
+// WALK(t) and WALK(t-2) -> ORBIT(t) -> WALK(t) paced it together with the serial stage itself.  With LM = 4, LF = 3 (standard layout)
+// neither loop is ever waited for (tools/bottleneck.sh: MATCH, ORBIT, COMMIT at 0.01 - 0.04), at the price of 0.18 more hazard lanes
+// per tile for WALK; what paces the pipeline then is the busiest wavefront.  The lean layout (two blocks per CU hide each other's
+// waits) keeps LM = 3, LF = 2: measured 33.0 GB/s against 29.0 at 1 024 blocks.
+#ifndef TSQ_LM
+#define TSQ_LM 4
+#endif
+#ifndef TSQ_LF
+#define TSQ_LF 3
+#endif
+#ifndef TSQ_LM_LEAN
+#define TSQ_LM_LEAN 3
+#endif
+#ifndef TSQ_LF_LEAN
+#define TSQ_LF_LEAN 2
+#endif
 
 #include "tsq_common.cuh"
 #include "tsq_enc_util.cuh"
@@ -52,18 +71,24 @@ typedef __attribute__((address_space(3))) u32x2_t lds_u32x2_t;
 template <bool WINDOW>
 struct StageCfgT {
     static constexpr uint32_t THREADS = 1024;                     // sixteen wavefronts are launched, twelve work (see the kernel)
-    static constexpr uint32_t THREADS_LEAN = 768;                 // the lean layout launches the twelve working ones only
+    static constexpr uint32_t THREADS_LEAN = 768;                 // the lean layout launches its twelve working ones only (two workgroups of more do not fit a CU)
+    static constexpr bool SPLIT_IN = WINDOW;                      // the in-tile twin search on a wavefront of its own (IN)
+    static constexpr bool DUAL_BUILDER = WINDOW;                  // two BUILDER wavefronts take the items alternately
     static constexpr uint32_t EQ = 64, EV_WORDS = 4;              // events between WALK and ACCOUNT
     static constexpr uint32_t Q = WINDOW ? 16 : 8;                // items between ACCOUNT and BUILDER (the queue is never full: profiles/r03_encoder_spin_counts.txt)
     static constexpr uint32_t ITEM_WORDS = 80;
     static constexpr uint32_t RING = 256;                          // symbol records between BUILDER and EMIT (four batches)
-    static constexpr uint32_t R = WINDOW ? 10 : 8;                // tile records in flight (every stage waits less with ten; the lean layout has room for eight)
-    static constexpr uint32_t OWN_MASK = 0x7FFFu;                 // owner image: hash folded to 15 bits
+    static constexpr uint32_t LM = WINDOW ? TSQ_LM : TSQ_LM_LEAN, LF = WINDOW ? TSQ_LF : TSQ_LF_LEAN;
+    static_assert((LM == 3u || LM == 4u) && LF >= 2u && LF < LM, "lags");
+    static constexpr uint32_t R = LM == 3u ? (WINDOW ? 10 : 8) : 10;   // tile records in flight (HASH runs at most R - LM tiles ahead of WALK)
+    static constexpr uint32_t OWN_MASK = (WINDOW || LM == 3u) ? 0x7FFFu : 0x3FFFu;   // owner image: hash folded to 15 bits (14 in the lean layout when it keeps ten records)
     static constexpr uint32_t WIN = 71168;                        // input window ring: the last 64 KiB of input and what SCAN is ahead of MATCH (at most R tiles; a multiple of 64)
     static constexpr uint32_t W16 = 16;                           // word offset of the uint4-per-lane input words
     static constexpr uint32_t ARR = 16 + 256;                     // word offset of the per-lane words: four groups of four words per lane
     static constexpr uint32_t REC_WORDS = ARR + 16 * 64;
-    static constexpr uint32_t off_owner = 0;                                   // u8[65536]
+    // bucket of a hash in the owner image (a multiplicative fold instead of the mask was measured: no fewer rounds in TWINS, no gain)
+    static __device__ __forceinline__ uint32_t fold(uint32_t h) { return h & OWN_MASK; }
+    static constexpr uint32_t off_owner = 0;                                   // u8[OWN_MASK + 1]
     static constexpr uint32_t off_queue = OWN_MASK + 1u;                       // u32[Q * ITEM_WORDS]
     static constexpr uint32_t off_ring = off_queue + Q * ITEM_WORDS * 4;       // u32[RING]
     static constexpr uint32_t off_rec = off_ring + RING * 4;                   // u32[R * REC_WORDS]
@@ -75,15 +100,16 @@ struct StageCfgT {
 };
 // ctl words: 0 queue head, 1 queue tail, 2 tiles with twin masks, 3 / 35 even / odd tiles matched, 4 / 15 even / odd tiles with orbits,
 //            5 tiles walked, 6 stop, 7..9 BUILDER/EMIT (tsq_enc_builder.cuh), 10..14 WALK/ACCOUNT events, 33 tiles committed, 34 tiles hashed,
-// record: header words 0,1 = lanes that have an earlier twin inside the tile (TWINS), 2,3 = the lanes the parse visited (WALK)
+// record: header words 2,3 = the lanes the parse visited (WALK)
 //         per-lane words, in four groups of four: group g of lane l is the 16-byte LDS word at ARR + g * 256 + l * 4, so that a stage
 //         reads or writes a whole group (or half of one) with ONE LDS instruction -- the LDS pipe is what the twelve wavefronts share,
 //         and a 4-byte access per lane costs it as much as an 8-byte one and half of a 16-byte one:
-//           A: spanword | candidate | nibble << 24 | orbit halt | orbit mask lo        (MATCH, ORBIT -> WALK, ACCOUNT)
-//           B: orbit mask hi | nearest twin's word (NEAR) | twins in this tile (earlier lanes) lo, hi
+//           A: spanword | candidate | nibble << 24 | orbit mask lo, hi                 (MATCH, ORBIT -> WALK, ACCOUNT)
+//           B: owner word (HASH -> TWINS), then the nearest twin's word (NEAR) | twins in this tile (earlier lanes) lo, hi | hash
 //           C: twins in tile t-1 lo, hi | twins in tile t-2 lo, hi                     (TWINS -> NEAR, MATCH, ORBIT, WALK)
-//           D: hash | twins in tile t-3 lo, hi | owner word (HASH -> TWINS)
-// spanword: natural span (bits 0..7) | hard (8) | has a twin (9) | certain match (10) | near twin (11) | twins of t-2 settled (12) | common prefix (16..23)
+//           D: twins in tile t-3 lo, hi | twins in tile t-4 lo, hi
+// spanword: natural span (bits 0..7) | hard (8) | has a twin (9) | certain match (10) | near twin (11) | twins of the late-fix tiles settled (12) |
+//           common prefix (16..23) | orbit halt (24..31: ORBIT)
 enum : uint32_t { kGA = 0, kGB = 256, kGC = 512, kGD = 768 };
 __device__ __forceinline__ u32x4_t lds_ld4(volatile lds_u32_t* p) { return *(volatile lds_u32x4_t*)p; }
 __device__ __forceinline__ u32x2_t lds_ld2(volatile lds_u32_t* p) { return *(volatile lds_u32x2_t*)p; }
@@ -92,7 +118,7 @@ __device__ __forceinline__ void lds_st2(volatile lds_u32_t* p, uint32_t a, uint3
 // events between WALK and ACCOUNT, and their ctl words (10 events produced, 11 consumed, 12 queries answered, 13 the answer,
 // 14 the tile ACCOUNT works on: the tiles before it are accounted)
 enum : uint32_t { kEvSeg = 1, kEvHaz = 2, kEvEnd = 3 };
-enum : uint32_t { kCtlEvHead = 10, kCtlEvTail = 11, kCtlReplies = 12, kCtlReplyValue = 13, kCtlAccounted = 14, kCtlOrbitOdd = 15, kCtlCommitted = 33, kCtlHashed = 34, kCtlMatchedOdd = 35, kCtlNear = 36 };
+enum : uint32_t { kCtlEvHead = 10, kCtlEvTail = 11, kCtlReplies = 12, kCtlReplyValue = 13, kCtlAccounted = 14, kCtlOrbitOdd = 15, kCtlCommitted = 33, kCtlHashed = 34, kCtlMatchedOdd = 35, kCtlNear = 36, kCtlIn = 37 };
 
 // Instrumented builds time only the spin loops (and only when they actually spin): s_memtime costs a few
 // hundred cycles, so finer timing distorts the pipeline it measures.  busy = total - waited.
@@ -209,10 +235,8 @@ __device__ __forceinline__ void stage_hash(const uint8_t* src, uint64_t avail, u
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
     const uint32_t n_tiles = (n >> 6) + 3u;            // visits reach at most n + 63
-    uint32_t hf_m1 = 0, hf_m2 = 0, hf_m3 = 0;           // folded hashes of tiles t-1 .. t-3 (per lane)
-    uint32_t id = 1;                                    // (t % 3) + 1: which of the three live tiles an owner tag names
     uint32_t wbase = 0;                                 // (t * 64) % WIN
-    uint32_t parsed_seen = 0, accounted_seen = 0, committed_seen = 0;
+    uint32_t parsed_seen = 0, accounted_seen = 0, committed_seen = 0, twinned_seen = 0;
 #ifdef TSQ_STATS
     unsigned long long st_[32] = {0};
 #endif
@@ -227,20 +251,22 @@ __device__ __forceinline__ void stage_hash(const uint8_t* src, uint64_t avail, u
 #pragma unroll
     for (uint32_t d = 0; d < D; ++d) w_q[d] = ld128z(src, (uint64_t)lane + 64u * d, avail);
     auto one_tile = [&](uint32_t t, const uint4 w16) -> bool {
-        // the slot of tile t-R is free once WALK has finished tile t-R+2 (it reads the words of two tiles back) and ACCOUNT and
-        // COMMIT are past tile t-R
-        if (t + 3u > StageCfg::R && !stage_wait_seen(ctl, 5, t + 3u - StageCfg::R, parsed_seen, 0)) return false;
+        // the slot of tile t-R is free once WALK has finished tile t-R+LM-1 (it reads the words of LM-1 tiles back), ACCOUNT and
+        // COMMIT are past tile t-R, and TWINS has finished tile t-R+LM (tile q's masks are inherited from the records of tiles q-1 .. q-LM)
+        if (t + StageCfg::LM > StageCfg::R && !stage_wait_seen(ctl, 5, t + StageCfg::LM - StageCfg::R, parsed_seen, 0)) return false;
         if (t + 1u > StageCfg::R && !stage_wait_seen(ctl, kCtlAccounted, t + 1u - StageCfg::R, accounted_seen, 0)) return false;
         if (t + 1u > StageCfg::R && !stage_wait_seen(ctl, kCtlCommitted, t + 1u - StageCfg::R, committed_seen, 0)) return false;
+        if (t + StageCfg::LM + 1u > StageCfg::R && !stage_wait_seen(ctl, 2, t + StageCfg::LM + 1u - StageCfg::R, twinned_seen, 0)) return false;
         TSQ_TRACE(0, t);
         const uint32_t h = hash4(w16.x);
-        const uint32_t hf = h & StageCfg::OWN_MASK;
-        const uint32_t tag = (id << 6) | lane;          // never 0: the image starts zeroed
+        const uint32_t hf = StageCfg::fold(h);
+        // The owner image: per folded hash, the last lane that had it and the low two bits of its tile number.  Nothing is ever
+        // retired: an entry is taken for what it says -- a lane one to four tiles back -- and TWINS checks it against that lane's own
+        // hash: a lane that really owns the bucket has this folded hash; the zero the image starts with and entries older than four
+        // tiles name a lane that (but for a coincidence, which is settled exactly like any fold collision) has not.
+        const uint32_t tag = ((t & 3u) << 6) | lane;
         volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
-        // The bucket's owner: the most recent lane of tiles t-1 .. t-3 with this folded hash (tile t-3 has tile t's id; nothing of
-        // tile t is in the image yet).  Then the entries of tile t-3 retire, unless a later tile has taken the bucket over.
         const uint32_t before = owner[hf];
-        if (t >= 3u && ((uint32_t)owner[hf_m3] >> 6) == id) owner[hf_m3] = 0;
         owner[hf] = (uint8_t)tag;
         const uint32_t after = owner[hf];
         {
@@ -253,13 +279,11 @@ __device__ __forceinline__ void stage_hash(const uint8_t* src, uint64_t avail, u
             }
         }
         volatile lds_u32_t* arr = rec + StageCfg::ARR + lane * 4u;
-        // group D: hash | (twins in t-3: TWINS) | owner before | this tile's id | another lane of the tile took the bucket
-        lds_st4(arr + kGD, h, 0u, 0u, before | (id << 8) | (after != tag ? 0x1000u : 0u));
+        // group B: owner before | another lane of the tile took the bucket; (twins in the tile: TWINS); hash
+        lds_st4(arr + kGB, before | (after != tag ? 0x10000u : 0u), 0u, 0u, h);
         TSQ_TRACE(1, t);
         TSQ_DELAY(0);
         stage_publish(ctl, kCtlHashed, t + 1u, lane);
-        hf_m3 = hf_m2; hf_m2 = hf_m1; hf_m1 = hf;
-        id = id == 3u ? 1u : id + 1u;
         wbase = wbase + 64u == StageCfg::WIN ? 0u : wbase + 64u;
         return true;
     };
@@ -281,68 +305,109 @@ __device__ __forceinline__ void stage_hash(const uint8_t* src, uint64_t avail, u
 #endif
 }
 
+// The twins inside the tile: for each lane the mask of EARLIER lanes with the same hash (one round per group of equal hashes among the
+// lanes whose bucket another lane of the tile took).
+__device__ __forceinline__ uint64_t in_tile_twins(uint32_t h, uint32_t own, uint64_t below_me)
+{
+    uint64_t twin_in = 0;
+    uint64_t shared = __ballot((own & 0x10000u) != 0u);
+    while (shared) {
+        const uint32_t hl = rdlane(h, lsb64(shared));
+        const uint64_t grp = __ballot(h == hl);
+        if (h == hl) twin_in = grp & below_me;
+        shared &= ~grp;
+    }
+    return twin_in;
+}
+
+// IN: the twins inside the tile -- for each lane the mask of EARLIER lanes with the same hash.  Independent from tile to tile, so it
+// has a wavefront of its own in the standard layout (it was TWINS' data-dependent loop: one round per group of equal hashes, 2.3 rounds
+// per tile on text).  The lean layout keeps it inside TWINS: two workgroups share a CU only with at most twelve wavefronts each.
 template <bool WINDOW>
-__device__ __forceinline__ void stage_twins(uint32_t n, lds_u8_t* lds, uint32_t lane)
+__device__ __forceinline__ void stage_in(uint32_t n, lds_u8_t* lds, uint32_t lane)
 {
     using StageCfg = StageCfgT<WINDOW>;
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
     const uint32_t n_tiles = (n >> 6) + 3u;
-    uint32_t h_m1 = 0xFFFFFFFFu, h_m2 = 0xFFFFFFFFu, h_m3 = 0xFFFFFFFFu;   // hashes of tiles t-1 .. t-3 (per lane)
-    uint32_t hashed_seen = 0;
+    uint32_t hashed_seen = 0, slot = 0;
+    const uint64_t below_me = below(lane);
 #ifdef TSQ_STATS
     unsigned long long st_[32] = {0};
 #endif
     TSQ_BEGIN();
-    for (uint32_t t = 0; t < n_tiles; ++t) {
+    for (uint32_t t = 0; t < n_tiles; ++t, slot = slot + 1u == StageCfg::R ? 0u : slot + 1u) {
         if (!stage_wait_seen(ctl, kCtlHashed, t + 1u, hashed_seen, 0)) break;
-        volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
-        volatile lds_u32_t* rec_m1 = recs + ((t + StageCfg::R - 1u) % StageCfg::R) * StageCfg::REC_WORDS;
-        volatile lds_u32_t* rec_m2 = recs + ((t + StageCfg::R - 2u) % StageCfg::R) * StageCfg::REC_WORDS;
-        volatile lds_u32_t* rec_m3 = recs + ((t + StageCfg::R - 3u) % StageCfg::R) * StageCfg::REC_WORDS;
+        volatile lds_u32_t* arr = recs + slot * StageCfg::REC_WORDS + StageCfg::ARR + lane * 4u;
+        const u32x4_t gb = lds_ld4(arr + kGB);
+        const uint32_t h = gb.w, own = gb.x;
+        const uint64_t twin_in = in_tile_twins(h, own, below_me);
+        lds_st2(arr + kGB + 1u, (uint32_t)twin_in, (uint32_t)(twin_in >> 32));
+        TSQ_DELAY(10);
+        stage_publish(ctl, kCtlIn, t + 1u, lane);
+    }
+#ifdef TSQ_STATS
+    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[34] = st_[22]; g_enc_stats[57] = st_[0]; g_enc_stats[58] = TSQ_TOTAL(); }
+#endif
+}
+
+template <bool WINDOW>
+__device__ __forceinline__ void stage_twins(uint32_t n, lds_u8_t* lds, uint32_t lane)
+{
+    using StageCfg = StageCfgT<WINDOW>;
+    constexpr uint32_t LM = StageCfg::LM;
+    volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
+    lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
+    const uint32_t n_tiles = (n >> 6) + 3u;
+    uint32_t h_m1 = 0xFFFFFFFFu, h_m2 = 0xFFFFFFFFu, h_m3 = 0xFFFFFFFFu, h_m4 = 0xFFFFFFFFu;   // hashes of tiles t-1 .. t-4 (per lane)
+    uint32_t hashed_seen = 0, slot = 0;
+#ifdef TSQ_STATS
+    unsigned long long st_[32] = {0};
+#endif
+    TSQ_BEGIN();
+    for (uint32_t t = 0; t < n_tiles; ++t, slot = slot + 1u == StageCfg::R ? 0u : slot + 1u) {
+        if (!stage_wait_seen(ctl, StageCfg::SPLIT_IN ? kCtlIn : kCtlHashed, t + 1u, hashed_seen, 0)) break;   // (IN has finished the tile, so HASH has)
+        volatile lds_u32_t* rec = recs + slot * StageCfg::REC_WORDS;
         volatile lds_u32_t* arr = rec + StageCfg::ARR + lane * 4u;
-        const u32x4_t gd = lds_ld4(arr + kGD);
-        const uint32_t h = gd.x, own = gd.w;
+        const u32x4_t gb = lds_ld4(arr + kGB);
+        const uint32_t h = gb.w, own = gb.x;
         const uint32_t before = own & 0xFFu;
-        const uint32_t id = (own >> 8) & 3u;
-        const uint32_t id_m1 = id == 1u ? 3u : id - 1u; // the id of tile t-1 (the third one is tile t-2's)
-        // ---- twins in the three previous tiles (t-1, t-2: the parser's business; t-3: MATCH folds its visited lanes into the
-        // candidates; older tiles are in the table).  If the owner's hash is this lane's hash, this lane's twins are the owner and
-        // the owner's own twins (already exact, by induction): no search.  If it is another hash (a fold collision: 192 live
-        // entries in 32 K buckets), a twin may hide behind it: settled with ballots below.
-        uint64_t twin_p1 = 0, twin_p2 = 0, twin_p3 = 0;
+        if (!StageCfg::SPLIT_IN) {
+            const uint64_t twin_in = in_tile_twins(h, own, below(lane));
+            lds_st2(arr + kGB + 1u, (uint32_t)twin_in, (uint32_t)(twin_in >> 32));
+        }
+        // ---- twins in the LM previous tiles (t-1 .. t-LM+1: the parser's business; t-LM: MATCH folds its visited lanes into the
+        // candidates; older tiles are in the table).  If the bucket's owner -- the MOST RECENT lane with this folded hash, d tiles back --
+        // has this lane's hash, this lane's twins are the owner and the owner's own twins (already exact, by induction): no search.
+        // If it has another hash (a fold collision), a twin may hide behind it: settled with ballots below.
+        uint64_t twin_p1 = 0, twin_p2 = 0, twin_p3 = 0, twin_p4 = 0;
         bool unsure = false;
-        if (__ballot(before != 0u) != 0ull) {
+        const uint32_t d0 = (t - (before >> 6)) & 3u;
+        const uint32_t d = d0 ? d0 : 4u;                                          // how many tiles back the owner says it is
+        const bool live = d <= t && d <= LM;
+        if (__ballot(live) != 0ull) {
             const uint32_t q = before & 63u;
-            const uint32_t bid = before >> 6;
-            const bool in_p1 = bid == id_m1, in_p3 = bid == id;
-            volatile lds_u32_t* qa = (in_p1 ? rec_m1 : in_p3 ? rec_m3 : rec_m2) + StageCfg::ARR + q * 4u;
-            const uint32_t hq = qa[kGD];
-            const u32x2_t qi = lds_ld2(qa + kGB + 2u);
+            const uint32_t dd = live ? d : 1u;
+            const uint32_t qslot = slot >= dd ? slot - dd : slot + StageCfg::R - dd;
+            volatile lds_u32_t* qa = recs + qslot * StageCfg::REC_WORDS + StageCfg::ARR + q * 4u;
+            const u32x4_t qb = lds_ld4(qa + kGB);
             const u32x4_t qc = lds_ld4(qa + kGC);
-            const uint64_t q_in = (uint64_t)qi.x | ((uint64_t)qi.y << 32);
+            const uint32_t hq = qb.w;
+            const uint64_t q_in = (uint64_t)qb.y | ((uint64_t)qb.z << 32);
             const uint64_t q_p1 = (uint64_t)qc.x | ((uint64_t)qc.y << 32);
             const uint64_t q_p2 = (uint64_t)qc.z | ((uint64_t)qc.w << 32);
-            const bool same = before != 0u && hq == h;
-            unsure = before != 0u && hq != h;
+            uint64_t q_p3 = 0;
+            if (LM == 4u) { const u32x2_t qd = lds_ld2(qa + kGD); q_p3 = (uint64_t)qd.x | ((uint64_t)qd.y << 32); }
+            const bool owns = live && StageCfg::fold(hq) == StageCfg::fold(h);      // the named lane has this folded hash: the entry is what it says
+            const bool same = owns && hq == h;
+            unsure = owns && hq != h;
             const uint64_t chain = q_in | (1ull << q);
             if (same) {
-                twin_p1 = in_p1 ? chain : 0ull;
-                twin_p2 = in_p1 ? q_p1 : in_p3 ? 0ull : chain;
-                twin_p3 = in_p1 ? q_p2 : in_p3 ? chain : q_p1;
-            }
-        }
-        // twins inside the tile: for each lane the mask of EARLIER lanes with the same hash
-        uint64_t twin_in = 0, twins_here = 0;
-        {
-            uint64_t shared = __ballot((own & 0x1000u) != 0u);
-            while (shared) {
-                TSQ_CNT(22, 1);
-                const uint32_t hl = rdlane(h, lsb64(shared));
-                const uint64_t grp = __ballot(h == hl);
-                if (h == hl) twin_in = grp & below(lane);
-                twins_here |= grp & (grp - 1ull);
-                shared &= ~grp;
+                // twins k tiles back: none for k < d, the owner and its in-tile twins for k = d, the owner's twins k - d tiles before ITS tile beyond
+                twin_p1 = d == 1u ? chain : 0ull;
+                twin_p2 = d == 2u ? chain : d == 1u ? q_p1 : 0ull;
+                twin_p3 = d == 3u ? chain : d == 2u ? q_p1 : d == 1u ? q_p2 : 0ull;
+                if (LM == 4u) twin_p4 = d == 4u ? chain : d == 3u ? q_p1 : d == 2u ? q_p2 : q_p3;
             }
         }
         {
@@ -352,31 +417,30 @@ __device__ __forceinline__ void stage_twins(uint32_t n, lds_u8_t* lds, uint32_t 
                 TSQ_CNT(21, 1);
                 const uint32_t hl = rdlane(h, lsb64(maybe));
                 const uint64_t g1 = __ballot(h_m1 == hl), g2 = __ballot(h_m2 == hl), g3 = __ballot(h_m3 == hl);
+                const uint64_t g4 = LM == 4u ? __ballot(h_m4 == hl) : 0ull;
                 const uint64_t grp_cur = __ballot(h == hl);
-                if (h == hl) { twin_p1 = g1; twin_p2 = g2; twin_p3 = g3; }
+                if (h == hl) { twin_p1 = g1; twin_p2 = g2; twin_p3 = g3; twin_p4 = g4; }
                 maybe &= ~grp_cur;
             }
         }
-        if (lane == 0) { rec[0] = (uint32_t)twins_here; rec[1] = (uint32_t)(twins_here >> 32); }
-        lds_st2(arr + kGB + 2u, (uint32_t)twin_in, (uint32_t)(twin_in >> 32));
         lds_st4(arr + kGC, (uint32_t)twin_p1, (uint32_t)(twin_p1 >> 32), (uint32_t)twin_p2, (uint32_t)(twin_p2 >> 32));
-        lds_st2(arr + kGD + 1u, (uint32_t)twin_p3, (uint32_t)(twin_p3 >> 32));
+        lds_st4(arr + kGD, (uint32_t)twin_p3, (uint32_t)(twin_p3 >> 32), (uint32_t)twin_p4, (uint32_t)(twin_p4 >> 32));
         TSQ_TRACE(2, t);
         TSQ_DELAY(1);
         stage_publish(ctl, 2, t + 1u, lane);
-        h_m3 = h_m2; h_m2 = h_m1; h_m1 = h;
+        h_m4 = h_m3; h_m3 = h_m2; h_m2 = h_m1; h_m1 = h;
     }
 #ifdef TSQ_STATS
-    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[48] = st_[0]; g_enc_stats[49] = TSQ_TOTAL(); g_enc_stats[32] = st_[20]; g_enc_stats[33] = st_[21]; g_enc_stats[34] = st_[22]; }
+    if (blockIdx.x == 0 && lane == 0) { g_enc_stats[48] = st_[0]; g_enc_stats[49] = TSQ_TOTAL(); g_enc_stats[32] = st_[20]; g_enc_stats[33] = st_[21]; }
 #endif
 }
 
 // ---------------------------------------------------------------------------------------------- NEAR
-// Off the critical loop, two or three tiles ahead of WALK: for every lane that has a twin in the window (its own tile and the two
+// Off the critical loop, tiles ahead of WALK: for every lane that has a twin in the window (its own tile and the LM-1
 // before), the common prefix with its NEAREST twin.  When WALK meets a hazard lane, the candidate is the most recent VISITED twin;
 // five times out of six that is the nearest twin, and then the prefix is here already (no LDS round trip and no byte compare on
 // the serial stage).  Word per lane (it takes the place of HASH's owner word, which TWINS has consumed by now):
-//   bit 15 valid | tiles back (0..2) << 12 | twin's lane << 6 | common prefix (0..16)
+//   bit 15 valid | tiles back (0..3) << 12 | twin's lane << 6 | common prefix (0..16)
 template <bool EXT, bool WINDOW>
 __device__ __forceinline__ void stage_near(uint32_t n, lds_u8_t* lds, uint32_t lane)
 {
@@ -393,23 +457,25 @@ __device__ __forceinline__ void stage_near(uint32_t n, lds_u8_t* lds, uint32_t l
         if (!stage_wait_seen(ctl, 2, t + 1u, scanned_seen, 0)) break;
         volatile lds_u32_t* rec = recs + slot * StageCfg::REC_WORDS;
         volatile lds_u32_t* arr = rec + StageCfg::ARR + lane * 4u;
-        const u32x2_t gi = lds_ld2(arr + kGB + 2u);
+        const u32x2_t gi = lds_ld2(arr + kGB + 1u);
         const u32x4_t gc = lds_ld4(arr + kGC);
-        const uint32_t tin_lo = gi.x, tin_hi = gi.y, tp1_lo = gc.x, tp1_hi = gc.y, tp2_lo = gc.z, tp2_hi = gc.w;
-        const bool in0 = (tin_lo | tin_hi) != 0u, in1 = (tp1_lo | tp1_hi) != 0u, in2 = (tp2_lo | tp2_hi) != 0u;
+        u32x2_t gd; gd.x = 0; gd.y = 0;
+        if (StageCfg::LM == 4u) gd = lds_ld2(arr + kGD);
+        const uint32_t tin_lo = gi.x, tin_hi = gi.y, tp1_lo = gc.x, tp1_hi = gc.y, tp2_lo = gc.z, tp2_hi = gc.w, tp3_lo = gd.x, tp3_hi = gd.y;
+        const bool in0 = (tin_lo | tin_hi) != 0u, in1 = (tp1_lo | tp1_hi) != 0u, in2 = (tp2_lo | tp2_hi) != 0u, in3 = (tp3_lo | tp3_hi) != 0u;
         uint32_t word = 0;
-        if (__ballot(in0 || in1 || in2) != 0ull) {
-            const uint32_t m_lo = in0 ? tin_lo : in1 ? tp1_lo : tp2_lo, m_hi = in0 ? tin_hi : in1 ? tp1_hi : tp2_hi;
+        if (__ballot(in0 || in1 || in2 || in3) != 0ull) {
+            const uint32_t m_lo = in0 ? tin_lo : in1 ? tp1_lo : in2 ? tp2_lo : tp3_lo, m_hi = in0 ? tin_hi : in1 ? tp1_hi : in2 ? tp2_hi : tp3_hi;
             const uint32_t q = m_hi ? 63u - (uint32_t)__builtin_clz(m_hi) : 31u - (uint32_t)__builtin_clz(m_lo | 1u);
-            const uint32_t back = in0 ? 0u : in1 ? 1u : 2u;
+            const uint32_t back = in0 ? 0u : in1 ? 1u : in2 ? 2u : 3u;
             const uint32_t qslot = slot >= back ? slot - back : slot + StageCfg::R - back;
             const u32x4_t a = *(volatile lds_u32x4_t*)(rec + StageCfg::W16 + lane * 4u);
             const u32x4_t b = *(volatile lds_u32x4_t*)(recs + qslot * StageCfg::REC_WORDS + StageCfg::W16 + q * 4u);
             const uint32_t k = prefix16(make_uint4(a.x, a.y, a.z, a.w), make_uint4(b.x, b.y, b.z, b.w));
             // (with extensions a prefix of 16 may go on: WALK takes the long way round for those)
-            if ((in0 || in1 || in2) && !(EXT && k >= 16u)) word = 0x8000u | (back << 12) | (q << 6) | k;
+            if ((in0 || in1 || in2 || in3) && !(EXT && k >= 16u)) word = 0x8000u | (back << 12) | (q << 6) | k;
         }
-        arr[kGB + 1u] = word;
+        arr[kGB] = word;
         TSQ_DELAY(2);
         stage_publish(ctl, kCtlNear, t + 1u, lane);
     }
@@ -426,6 +492,7 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
     constexpr uint32_t kDMin = EXT ? 128u : 64u;
+    constexpr uint32_t LM = StageCfg::LM;
     const uint32_t tail_from = n >= 5u ? n - 5u : 0u;
     const uint32_t n_tiles = (n >> 6) + 3u;
     // two MATCH wavefronts take the even and the odd tiles (nothing is carried from tile to tile)
@@ -441,46 +508,47 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         TSQ_TRACE(3, t);
         volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
         volatile lds_u32_t* arr = rec + StageCfg::ARR + lane * 4u;
-        const u32x4_t gd = lds_ld4(arr + kGD);
+        const u32x4_t gb = lds_ld4(arr + kGB);
         const u32x4_t wv = *(volatile lds_u32x4_t*)(rec + StageCfg::W16 + lane * 4u);
-        const u32x2_t gi = lds_ld2(arr + kGB + 2u);
         const u32x4_t gc = lds_ld4(arr + kGC);
-        const uint32_t h = gd.x;
+        const u32x4_t gd = lds_ld4(arr + kGD);
+        const uint32_t h = gb.w;
         const uint4 w16 = make_uint4(wv.x, wv.y, wv.z, wv.w);
-        const uint64_t twin_in = (uint64_t)gi.x | ((uint64_t)gi.y << 32);
+        const uint64_t twin_in = (uint64_t)gb.y | ((uint64_t)gb.z << 32);
         const uint64_t twin_p1 = (uint64_t)gc.x | ((uint64_t)gc.y << 32);
-        const uint32_t tp2_any = gc.z | gc.w;
-        const uint32_t tp3_lo = gd.y, tp3_hi = gd.z;
+        // twins in the other tiles WALK looks after (t-2 .. t-LM+1), and the mask MATCH patches with (tile t-LM)
+        const uint32_t tpw_any = LM == 4u ? (gc.z | gc.w | gd.x | gd.y) : (gc.z | gc.w);
+        const uint32_t tpm_lo = LM == 4u ? gd.z : gd.x, tpm_hi = LM == 4u ? gd.w : gd.y;
         MREG_END(10);
         MREG_BEGIN(12);
-        // ---- the table holds the visits of tiles <= t-4 (the COMMIT wave has published them: its stores are complete and the
+        // ---- the table holds the visits of tiles <= t-LM-1 (the COMMIT wave has published them: its stores are complete and the
         //      wavefronts of a workgroup share the vector L1): gather from it right away, without waiting for the parser ...
-        if (t >= 4u && !stage_wait_seen(ctl, kCtlCommitted, t - 3u, committed_seen, 3)) break;
+        if (t >= LM + 1u && !stage_wait_seen(ctl, kCtlCommitted, t - LM, committed_seen, 3)) break;
         TSQ_TRACE(10, t);
         const uint32_t tv_old = table[h];                // (a plain load: an atomic one is waited for on the spot, and the gather's latency must stay hidden)
         MREG_END(12);
         MREG_BEGIN(11);
-        // ... and bring the entries up to "visits of tiles <= t-3" once the parser has finished tile t-3: a lane with a
+        // ... and bring the entries up to "visits of tiles <= t-LM" once the parser has finished tile t-LM: a lane with a
         // visited twin there (SCAN's exact mask) takes the most recent one -- what the committed table would hold --, the others
         // keep theirs.
         uint32_t tv = tv_old;
-        if (t >= 3u) {
-            volatile lds_u32_t* vis = recs + ((t - 3u) % StageCfg::R) * StageCfg::REC_WORDS + 2u;
+        if (t >= LM) {
+            volatile lds_u32_t* vis = recs + ((t - LM) % StageCfg::R) * StageCfg::REC_WORDS + 2u;
             uint32_t vis_lo, vis_hi;
             {   // (counter and visited mask requested together: one LDS round trip less on the lag loop)
                 const uint32_t seen_v = ((volatile lds_u32_t*)ctl)[5];
                 uint32_t a = vis[0], b = vis[1];
                 asm volatile("" ::: "memory");
-                if (uniform(seen_v) < t - 2u) {
-                    if (!stage_wait_tight(ctl, 5, t - 2u, 3)) break;
+                if (uniform(seen_v) < t - LM + 1u) {
+                    if (!stage_wait_tight(ctl, 5, t - LM + 1u, 3)) break;
                     a = vis[0]; b = vis[1];
                 }
                 vis_lo = uniform(a); vis_hi = uniform(b);
             }
             TSQ_TRACE(4, t);
-            const uint32_t hit_lo = tp3_lo & vis_lo, hit_hi = tp3_hi & vis_hi;
+            const uint32_t hit_lo = tpm_lo & vis_lo, hit_hi = tpm_hi & vis_hi;
             const uint32_t q = hit_hi ? 63u - (uint32_t)__builtin_clz(hit_hi) : 31u - (uint32_t)__builtin_clz(hit_lo | 1u);
-            if ((hit_lo | hit_hi) != 0u) tv = (((t - 3u) << 6) + q) & 0xFFFFu;
+            if ((hit_lo | hit_hi) != 0u) tv = (((t - LM) << 6) + q) & 0xFFFFu;
         }
         MREG_END(11);
         // ---- candidates of tile t
@@ -550,7 +618,7 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         // offset = origin - cand <= p - cand: a candidate closer than 4 bytes can never pass (offset-4) < 0xFFFB
         // (tsq_encode.cpp:100), whatever the pair origin: such a lane is a plain "no match", not a hazard
         const bool hard_l = (eq4 && !far_enough && dist >= 4u && !neart) || tail;
-        const bool twin_l = (twin_in | twin_p1) != 0ull || tp2_any != 0u;
+        const bool twin_l = (twin_in | twin_p1) != 0ull || tpw_any != 0u;
         lds_st2(arr + kGA, span_nat | (hard_l ? 0x100u : 0u) | (twin_l ? 0x200u : 0u) | (certain ? 0x400u : 0u) | (neart ? 0x800u : 0u) | (k0 << 16),
                 cand0 | (nib << 24));
 #ifdef TSQ_STATS
@@ -586,10 +654,9 @@ __device__ __forceinline__ void stage_commit(uint32_t n, uint16_t* table, lds_u8
         if (!stage_wait(ctl, 5, t + 1u, 3)) break;
         volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
         volatile lds_u32_t* arr = rec + StageCfg::ARR + lane * 4u;
-        const uint32_t h = arr[kGD];
-        const u32x2_t gi = lds_ld2(arr + kGB + 2u);
-        const uint32_t tin_lo = gi.x, tin_hi = gi.y;
-        const uint64_t tw = (uint64_t)uniform(rec[0]) | ((uint64_t)uniform(rec[1]) << 32);   // lanes with an earlier twin inside the tile
+        const u32x4_t gb = lds_ld4(arr + kGB);
+        const uint32_t h = gb.w, tin_lo = gb.y, tin_hi = gb.z;
+        const uint64_t tw = __ballot((tin_lo | tin_hi) != 0u);                             // lanes with an earlier twin inside the tile
         lds_u32_t* visw = (lds_u32_t*)(rec + 2u);
         const uint64_t vis = (uint64_t)uniform(__hip_atomic_load(&visw[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) |
                              ((uint64_t)uniform(__hip_atomic_load(&visw[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) << 32);
@@ -622,6 +689,7 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
     constexpr uint32_t kDMin = EXT ? 128u : 64u;
+    constexpr uint32_t LM = StageCfg::LM, LF = StageCfg::LF;
     const uint32_t tail_from = n >= 5u ? n - 5u : 0u;
     const uint32_t n_tiles = (n >> 6) + 3u;
 #ifdef TSQ_STATS
@@ -633,33 +701,44 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
     for (uint32_t t = parity; t < n_tiles; t += 2u) {
         volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
         volatile lds_u32_t* arr = rec + StageCfg::ARR + lane * 4u;
-        // ---- late classification of lanes whose only twins are in tile t-2.  By now the parser has (almost always)
-        //      finished that tile, so which of those twins were visited is known: the most recent visited one IS the
-        //      candidate (tsq_encode.cpp:76-79), 65..191 bytes back.  Such a lane becomes an ordinary certain lane and
-        //      never reaches the parser's scalar path.  (Lanes that also have twins in tile t-1 or t stay hazards.)
+        // ---- late classification of lanes whose only twins are in tiles t-LF .. t-LM+1.  By now the parser has (almost always)
+        //      finished those tiles, so which of those twins were visited is known: the most recent visited one IS the
+        //      candidate (tsq_encode.cpp:76-79), 65 bytes or more back.  Such a lane becomes an ordinary certain lane and
+        //      never reaches the parser's scalar path.  (Lanes that also have nearer twins stay hazards.)
         //      All of this needs only SCAN's part of the record, so it runs while MATCH is still gathering tile t.
         uint32_t fix_sw = 0, fix_lw = 0;
-        bool fix = false, clear_tp2 = false;
-        if (TSQ_LATE_FIX && t >= 2u) {
+        bool fix = false, clear_far = false;
+        if (TSQ_LATE_FIX && t >= LF) {
             if (!stage_wait_seen(ctl, 2, t + 1u, scanned_seen, 6)) break;
             const u32x4_t gc = lds_ld4(arr + kGC);
-            const u32x2_t gi = lds_ld2(arr + kGB + 2u);
-            const uint32_t tp2_lo = gc.z, tp2_hi = gc.w;
-            const uint32_t nearer = gi.x | gi.y | gc.x | gc.y;
+            const u32x2_t gi = lds_ld2(arr + kGB + 1u);
+            u32x2_t gd; gd.x = 0; gd.y = 0;
+            if (LM == 4u) gd = lds_ld2(arr + kGD);
+            // masks of the tiles WALK looks after, nearest first: tp[1] .. tp[LM-1]
+            const uint32_t tp_lo[4] = {0u, gc.x, gc.z, gd.x}, tp_hi[4] = {0u, gc.y, gc.w, gd.y};
+            uint32_t nearer = gi.x | gi.y, far = 0;
+#pragma unroll
+            for (uint32_t k = 1; k < LM; ++k) { if (k < LF) nearer |= tp_lo[k] | tp_hi[k]; else far |= tp_lo[k] | tp_hi[k]; }
             const uint32_t p = (t << 6) + lane;
-            const bool only2 = (tp2_lo | tp2_hi) != 0u && nearer == 0u && p < tail_from;
-            if (__ballot(only2) != 0ull) {
-                if (!stage_wait_seen(ctl, 5, t - 1u, parsed_seen, 5)) break;                   // the parser has finished tile t-2
-                lds_u32_t* vis = (lds_u32_t*)(recs + ((t - 2u) % StageCfg::R) * StageCfg::REC_WORDS + 2u);
-                const uint32_t v2_lo = uniform(__hip_atomic_load(&vis[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                const uint32_t v2_hi = uniform(__hip_atomic_load(&vis[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                const uint32_t hit_lo = tp2_lo & v2_lo, hit_hi = tp2_hi & v2_hi;
-                clear_tp2 = only2;                       // visited or not, tile t-2 is settled for this lane
-                if (only2 && (hit_lo | hit_hi) != 0u) {
+            const bool only_far = far != 0u && nearer == 0u && p < tail_from;
+            if (__ballot(only_far) != 0ull) {
+                if (!stage_wait_seen(ctl, 5, t - LF + 1u, parsed_seen, 5)) break;              // the parser has finished tile t-LF
+                uint32_t hit_lo = 0, hit_hi = 0, back = 0;
+#pragma unroll
+                for (uint32_t k = LM - 1u; k >= LF; --k) {                                     // (the nearest tile last: it wins)
+                    lds_u32_t* vis = (lds_u32_t*)(recs + ((t - k) % StageCfg::R) * StageCfg::REC_WORDS + 2u);
+                    const uint32_t v_lo = uniform(__hip_atomic_load(&vis[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    const uint32_t v_hi = uniform(__hip_atomic_load(&vis[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    const uint32_t h_lo = tp_lo[k] & v_lo, h_hi = tp_hi[k] & v_hi;
+                    if ((h_lo | h_hi) != 0u) { hit_lo = h_lo; hit_hi = h_hi; back = k; }
+                }
+                clear_far = only_far;                    // visited or not, those tiles are settled for this lane
+                if (only_far && (hit_lo | hit_hi) != 0u) {
                     const uint32_t q = hit_hi ? 63u - (uint32_t)__builtin_clz(hit_hi) : 31u - (uint32_t)__builtin_clz(hit_lo);
-                    const uint32_t cand = (t << 6) - 128u + q;
+                    const uint32_t cand = (t << 6) - (back << 6) + q;
+                    const uint32_t tq = t - back;
                     const u32x4_t a = *(volatile lds_u32x4_t*)(rec + StageCfg::W16 + lane * 4u);
-                    const u32x4_t b = *(volatile lds_u32x4_t*)(recs + ((t - 2u) % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::W16 + q * 4u);
+                    const u32x4_t b = *(volatile lds_u32x4_t*)(recs + (tq % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::W16 + q * 4u);
                     const uint32_t k = prefix16(make_uint4(a.x, a.y, a.z, a.w), make_uint4(b.x, b.y, b.z, b.w));
                     // exact when the outcome cannot depend on the pair origin (as for the table's candidates) and, with
                     // extensions, when the first 16 bytes decide the length; otherwise the lane stays a hazard
@@ -669,25 +748,26 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
                         fix_sw = (eq4 ? nibble_span(nib) | 0x400u : 1u) | (k << 16);
                         fix_lw = cand | (nib << 24);
                         fix = true;
-                    } else clear_tp2 = false;
+                    } else clear_far = false;
                 }
             }
         }
-        // (counter and record word requested together, as in WALK: one LDS round trip less on the lag loop)
-        uint32_t sw;
+        // (counter and record words requested together, as in WALK: one LDS round trip less on the lag loop)
+        uint32_t sw, lw;
         {
             const uint32_t seen_v = ((volatile lds_u32_t*)ctl)[parity ? kCtlMatchedOdd : 3u];
-            sw = arr[kGA];
+            u32x2_t ga = lds_ld2(arr + kGA);
             asm volatile("" ::: "memory");
             if (uniform(seen_v) < t + 1u) {
                 if (!stage_wait_tight(ctl, parity ? kCtlMatchedOdd : 3u, t + 1u, 6)) break;
-                sw = arr[kGA];
+                ga = lds_ld2(arr + kGA);
             }
+            sw = ga.x; lw = ga.y;
         }
         TSQ_TRACE(11, t);
-        if (clear_tp2) fix_sw |= 0x1000u;
-        if (fix) { sw = fix_sw; lds_st2(arr + kGA, fix_sw, fix_lw); }
-        else if (clear_tp2) { sw |= 0x1000u; arr[kGA] = sw; }        // (SCAN's masks stay as they are: later tiles inherit from them)
+        if (clear_far) fix_sw |= 0x1000u;
+        if (fix) { sw = fix_sw; lw = fix_lw; }
+        else if (clear_far) sw |= 0x1000u;                          // (SCAN's masks stay as they are: later tiles inherit from them)
         // the whole orbit of every lane, by pointer doubling: `nx` = where the orbit started at this lane halts
         // (lane, or position past the tile: 7 bits | halted: bit 7), `orb` = the lanes it visits before that.
         // A hop halts when it lands on a hard lane or past the tile.  Twin lanes do not halt: the parser takes
@@ -707,8 +787,7 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
         }
         // (WALK also reads NEAR's word of the tile: NEAR runs tiles ahead, this wait is satisfied by what was read long ago)
         if (!stage_wait_seen(ctl, kCtlNear, t + 1u, near_seen, 6)) break;
-        lds_st2(arr + kGA + 2u, nx, (uint32_t)orb);
-        arr[kGB] = (uint32_t)(orb >> 32);
+        lds_st4(arr + kGA, sw | (nx << 24), lw, (uint32_t)orb, (uint32_t)(orb >> 32));
 #ifdef TSQ_STATS
         if (t >= 3u) { st_[24] += (uint32_t)((uint32_t)__builtin_amdgcn_s_memtime() - uniform(ctl[40u + ((t - 3u) & 7u)])); st_[25] += 1; }
 #endif
@@ -777,11 +856,12 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
     volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
     lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
     const uint32_t tail_from = uniform(n >= 5u ? n - 5u : 0u);
+    constexpr uint32_t LM = StageCfg::LM, LF = StageCfg::LF;
 
     uint32_t ev_head = 0, ev_tail_seen = 0, n_query = 0;
     uint32_t v = 1, done = 0;
     uint32_t last_m = 0;                 // where the most recent match symbol starts: no pair origin lies before it
-    uint64_t vall_p1 = 0, vall_p2 = 0;   // visited lanes of the two previous tiles
+    uint64_t vall_p1 = 0, vall_p2 = 0, vall_p3 = 0;   // visited lanes of the previous tiles (LM-1 of them are looked at)
 #ifdef TSQ_STATS
     unsigned long long st_[32] = {0};
 #endif
@@ -829,12 +909,14 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
             // (the serial stage polls without sleeping: a wake-up from s_sleep costs it up to 64 cycles per hand-off)
             const uint32_t orbit_word = (t & 1u) ? kCtlOrbitOdd : 4u;
             volatile lds_u32_t* arr = recs + rec_slot * StageCfg::REC_WORDS + StageCfg::ARR + lane * 4u;
-            uint32_t spanword, lane_word, nx, orb_lo, orb_hi, tin_lo, tin_hi, tp1_lo, tp1_hi, tp2r_lo, tp2r_hi, nearw;
+            uint32_t spanword, lane_word, nx, orb_lo, orb_hi, tin_lo, tin_hi, tp1_lo, tp1_hi, tp2r_lo, tp2r_hi, tp3r_lo = 0, tp3r_hi = 0, nearw;
             auto load_record = [&]() {
-                const u32x4_t ga = lds_ld4(arr + kGA), gb = lds_ld4(arr + kGB), gc = lds_ld4(arr + kGC);      // three LDS instructions
-                spanword = ga.x; lane_word = ga.y; nx = ga.z; orb_lo = ga.w;
-                orb_hi = gb.x; nearw = gb.y; tin_lo = gb.z; tin_hi = gb.w;
+                const u32x4_t ga = lds_ld4(arr + kGA), gb = lds_ld4(arr + kGB), gc = lds_ld4(arr + kGC);      // three LDS instructions (four with LM = 4)
+                spanword = ga.x; lane_word = ga.y; orb_lo = ga.z; orb_hi = ga.w;
+                nearw = gb.x; tin_lo = gb.y; tin_hi = gb.z;
                 tp1_lo = gc.x; tp1_hi = gc.y; tp2r_lo = gc.z; tp2r_hi = gc.w;
+                if (LM == 4u) { const u32x2_t gd = lds_ld2(arr + kGD); tp3r_lo = gd.x; tp3r_hi = gd.y; }
+                nx = spanword >> 24;
             };
             // The counter and the record's words are requested together: the LDS serves a wavefront's requests in order, so when the
             // counter (asked for first) says the record is there, the words that came back behind it are the record's; only when it is
@@ -856,15 +938,17 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
             }
             TSQ_CNT(15, 1);
             TSQ_TRACE(8, t);
-            const uint32_t settled = (spanword & 0x1000u) ? 0u : 0xFFFFFFFFu;     // ORBIT has settled the lane's twins in tile t-2
-            const uint32_t tp2_lo = tp2r_lo & settled, tp2_hi = tp2r_hi & settled;
+            const uint32_t settled = (spanword & 0x1000u) ? 0u : 0xFFFFFFFFu;     // ORBIT has settled the lane's twins in tiles t-LF .. t-LM+1
+            const uint32_t tp2_lo = LF <= 2u ? tp2r_lo & settled : tp2r_lo, tp2_hi = LF <= 2u ? tp2r_hi & settled : tp2r_hi;
+            const uint32_t tp3_lo = tp3r_lo & settled, tp3_hi = tp3r_hi & settled;
             const uint64_t hard = __ballot((spanword & 0x100u) != 0u);
             const uint64_t near_m = __ballot((spanword & 0x800u) != 0u);
             const uint64_t certain_m = __ballot((spanword & 0x400u) != 0u);
             uint64_t Vacc = 0;                   // visited lanes not yet handed to ACCOUNT
-            // a twin visited in the two previous tiles: fixed for the whole tile (kept per lane, it joins the in-tile test)
-            const uint32_t prev_hit = (tp1_lo & (uint32_t)vall_p1) | (tp1_hi & (uint32_t)(vall_p1 >> 32)) |
-                                      (tp2_lo & (uint32_t)vall_p2) | (tp2_hi & (uint32_t)(vall_p2 >> 32));
+            // a twin visited in the previous tiles: fixed for the whole tile (kept per lane, it joins the in-tile test)
+            uint32_t prev_hit = (tp1_lo & (uint32_t)vall_p1) | (tp1_hi & (uint32_t)(vall_p1 >> 32)) |
+                                (tp2_lo & (uint32_t)vall_p2) | (tp2_hi & (uint32_t)(vall_p2 >> 32));
+            if (LM == 4u) prev_hit |= (tp3_lo & (uint32_t)vall_p3) | (tp3_hi & (uint32_t)(vall_p3 >> 32));
             const uint32_t k0 = (spanword >> 16) & 0xFFu;
             const uint32_t cand0 = lane_word & 0xFFFFFFu;
 
@@ -921,7 +1005,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                 // (the most recent visited position with the lane's hash): five hazard lanes out of six, one readlane and a bit test.
                 const uint32_t nw = rdlane(nearw, L);
                 const uint32_t nback = (nw >> 12) & 3u, nq = (nw >> 6) & 63u;
-                const uint64_t nmask = s_sel64(nback, s_sel64(nback & 2u, vall_p2, vall_p1), vall);
+                const uint64_t nmask = s_sel64(nback, s_sel64(nback & 2u, s_sel64(nback & 1u, vall_p3, vall_p2), vall_p1), vall);
                 if ((nw >> 15) & (uint32_t)(nmask >> nq) & 1u) {
                     cand = base - (nback << 6) + nq;
                     k = nw & 63u;
@@ -936,9 +1020,10 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                     const uint64_t in_tile = ((uint64_t)rdlane(tin_lo, L) | ((uint64_t)rdlane(tin_hi, L) << 32)) & vall;
                     const uint64_t in_p1 = ((uint64_t)rdlane(tp1_lo, L) | ((uint64_t)rdlane(tp1_hi, L) << 32)) & vall_p1;
                     const uint64_t in_p2 = ((uint64_t)rdlane(tp2_lo, L) | ((uint64_t)rdlane(tp2_hi, L) << 32)) & vall_p2;
-                    if (in_tile | in_p1 | in_p2) {
-                        const uint64_t pick = in_tile ? in_tile : in_p1 ? in_p1 : in_p2;
-                        const uint32_t back = in_tile ? 0u : in_p1 ? 64u : 128u;
+                    const uint64_t in_p3 = LM == 4u ? ((uint64_t)rdlane(tp3_lo, L) | ((uint64_t)rdlane(tp3_hi, L) << 32)) & vall_p3 : 0ull;
+                    if (in_tile | in_p1 | in_p2 | in_p3) {
+                        const uint64_t pick = in_tile ? in_tile : in_p1 ? in_p1 : in_p2 ? in_p2 : in_p3;
+                        const uint32_t back = in_tile ? 0u : in_p1 ? 64u : in_p2 ? 128u : 192u;
                         const uint32_t pick_lane = msb64(pick);
                         cand = base - back + pick_lane;
                         const uint32_t tiles_back = back >> 6;
@@ -1033,7 +1118,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
         if (lane == 0) ctl[40u + (t & 7u)] = (uint32_t)__builtin_amdgcn_s_memtime();       // (the lag loop is timed from here)
 #endif
         TSQ_TRACE(9, t);
-        vall_p2 = vall_p1; vall_p1 = vall;
+        vall_p3 = vall_p2; vall_p2 = vall_p1; vall_p1 = vall;
         REG_END(7);
     }
 #ifdef TSQ_STATS
@@ -1070,7 +1155,11 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
             const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
 #endif
             while (head - tail_seen >= StageCfg::Q) {
-                tail_seen = uniform(__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                tail_seen = uniform(__hip_atomic_load(&ctl[kCtlTail0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (StageCfg::DUAL_BUILDER) {          // (each BUILDER wavefront publishes the next item it will take: every item below both is consumed)
+                    const uint32_t t1 = uniform(__hip_atomic_load(&ctl[kCtlTail1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    tail_seen = tail_seen < t1 ? tail_seen : t1;
+                }
                 if (head - tail_seen >= StageCfg::Q) { TSQ_SPIN_AT(ctl, 45u); __builtin_amdgcn_s_sleep(2); }
             }
 #ifdef TSQ_STATS
@@ -1325,10 +1414,10 @@ __global__ __launch_bounds__(1024) void enc_stage_kernel(const uint8_t* __restri
     //   SIMD 0: WALK, NEAR      SIMD 1: ORBIT even, MATCH even, HASH, BUILDER     SIMD 2: ORBIT odd, MATCH odd, TWINS, EMIT     SIMD 3: ACCOUNT, COMMIT
     // (measured: ACCOUNT next to WALK on SIMD 0 costs 8 to 13 ms -- WALK polls without sleeping and starves the wavefront whose
     //  answers it waits for; a third ORBIT wavefront +1.4 ms; s_setprio, COMMIT / EMIT / HASH on SIMD 0, NEAR on SIMD 2 or 3: within 0.3 %)
-    enum : uint32_t { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNone, kRoleMatch0, kRoleMatch1, kRoleBuilder, kRoleHash, kRoleTwins, kRoleEmit, kRoleCommit, kRoleNear };
+    enum : uint32_t { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNone, kRoleMatch0, kRoleMatch1, kRoleBuilder, kRoleHash, kRoleTwins, kRoleEmit, kRoleCommit, kRoleNear, kRoleIn, kRoleBuilder1 };
     // (the lean layout -- two workgroups per CU -- launches the twelve working wavefronts only: 2 x 16 do not fit a CU's wave slots)
     constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleCommit,
-                                        kRoleNone, kRoleHash, kRoleTwins, kRoleNone, kRoleNone, kRoleBuilder, kRoleEmit, kRoleNone };
+                                        kRoleNone, kRoleHash, kRoleTwins, kRoleIn, kRoleNone, kRoleBuilder, kRoleEmit, kRoleBuilder1 };
     // (lean layout, measured at 4 GiB: this placement 30.7 GB/s on text against 29.4 for the round's earlier one)
     constexpr uint32_t role_map_lean[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleBuilder,
                                              kRoleCommit, kRoleHash, kRoleTwins, kRoleEmit, kRoleNone, kRoleNone, kRoleNone, kRoleNone };
@@ -1364,11 +1453,13 @@ __global__ __launch_bounds__(1024) void enc_stage_kernel(const uint8_t* __restri
     else if (role == kRoleCommit) stage_commit<WINDOW>(n, table, lds3, lane);
     else if (role == kRoleHash) stage_hash<WINDOW>(src, avail, n, lds3, lane);
     else if (role == kRoleTwins) stage_twins<WINDOW>(n, lds3, lane);
+    else if (role == kRoleIn) stage_in<WINDOW>(n, lds3, lane);
     else if (role == kRoleNear) stage_near<EXT, WINDOW>(n, lds3, lane);
     else if (role == kRoleMatch0 || role == kRoleMatch1) stage_match<EXT, WINDOW>(src, avail, n, table, lds3, lane, role == kRoleMatch1 ? 1u : 0u);
     else if (role == kRoleOrbit0 || role == kRoleOrbit1) stage_orbit<EXT, WINDOW>(n, lds3, lane, role == kRoleOrbit1 ? 1u : 0u);
     else if (role == kRoleEmit) stream_emitter<StageCfg>(src, avail, out, lds3, lane, b, sizes, status);
-    else if (role == kRoleBuilder) stream_builder<StageCfg>(lds3, lane);
+    else if (role == kRoleBuilder) stream_builder<StageCfg>(lds3, lane, 0u);
+    else if (role == kRoleBuilder1) stream_builder<StageCfg>(lds3, lane, 1u);
 #ifdef TSQ_SPINS
     if (blockIdx.x == 0 && lane == 0) g_enc_spins[threadIdx.x >> 6] = reinterpret_cast<uint32_t*>(stage_lds + StageCfg::off_ctl)[48u + (threadIdx.x >> 6)];
     if (blockIdx.x == 0 && role == kRoleEmit && lane == 0) for (uint32_t q = 0; q < 4u; ++q) g_enc_spins[16u + q] = reinterpret_cast<uint32_t*>(stage_lds + StageCfg::off_ctl)[44u + q];   // (EMIT leaves last)
