@@ -105,7 +105,8 @@ struct StageCfgT {
 //         reads or writes a whole group (or half of one) with ONE LDS instruction -- the LDS pipe is what the twelve wavefronts share,
 //         and a 4-byte access per lane costs it as much as an 8-byte one and half of a 16-byte one:
 //           A: spanword | candidate | nibble << 24 | orbit mask lo, hi                 (MATCH, ORBIT -> WALK, ACCOUNT)
-//           B: owner word (HASH -> TWINS), then the nearest twin's word (NEAR) | twins in this tile (earlier lanes) lo, hi | hash
+//           B: owner word (HASH -> TWINS), then the nearest twin's word (NEAR) | hash | twins in this tile (earlier lanes) lo, hi
+//              (a two-word access at an odd word is a misaligned LDS access: ~40 cycles of the LDS pipe instead of 5 -- SQ_LDS_UNALIGNED_STALL)
 //           C: twins in tile t-1 lo, hi | twins in tile t-2 lo, hi                     (TWINS -> NEAR, MATCH, ORBIT, WALK)
 //           D: twins in tile t-3 lo, hi | twins in tile t-4 lo, hi
 // spanword: natural span (bits 0..7) | hard (8) | has a twin (9) | certain match (10) | near twin (11) | twins of the late-fix tiles settled (12) |
@@ -279,8 +280,8 @@ __device__ __forceinline__ void stage_hash(const uint8_t* src, uint64_t avail, u
             }
         }
         volatile lds_u32_t* arr = rec + StageCfg::ARR + lane * 4u;
-        // group B: owner before | another lane of the tile took the bucket; (twins in the tile: TWINS); hash
-        lds_st4(arr + kGB, before | (after != tag ? 0x10000u : 0u), 0u, 0u, h);
+        // group B: owner before | another lane of the tile took the bucket; hash; (twins in the tile: IN / TWINS)
+        lds_st4(arr + kGB, before | (after != tag ? 0x10000u : 0u), h, 0u, 0u);
         TSQ_TRACE(1, t);
         TSQ_DELAY(0);
         stage_publish(ctl, kCtlHashed, t + 1u, lane);
@@ -340,9 +341,9 @@ __device__ __forceinline__ void stage_in(uint32_t n, lds_u8_t* lds, uint32_t lan
         if (!stage_wait_seen(ctl, kCtlHashed, t + 1u, hashed_seen, 0)) break;
         volatile lds_u32_t* arr = recs + slot * StageCfg::REC_WORDS + StageCfg::ARR + lane * 4u;
         const u32x4_t gb = lds_ld4(arr + kGB);
-        const uint32_t h = gb.w, own = gb.x;
+        const uint32_t h = gb.y, own = gb.x;
         const uint64_t twin_in = in_tile_twins(h, own, below_me);
-        lds_st2(arr + kGB + 1u, (uint32_t)twin_in, (uint32_t)(twin_in >> 32));
+        lds_st2(arr + kGB + 2u, (uint32_t)twin_in, (uint32_t)(twin_in >> 32));
         TSQ_DELAY(10);
         stage_publish(ctl, kCtlIn, t + 1u, lane);
     }
@@ -370,11 +371,11 @@ __device__ __forceinline__ void stage_twins(uint32_t n, lds_u8_t* lds, uint32_t 
         volatile lds_u32_t* rec = recs + slot * StageCfg::REC_WORDS;
         volatile lds_u32_t* arr = rec + StageCfg::ARR + lane * 4u;
         const u32x4_t gb = lds_ld4(arr + kGB);
-        const uint32_t h = gb.w, own = gb.x;
+        const uint32_t h = gb.y, own = gb.x;
         const uint32_t before = own & 0xFFu;
         if (!StageCfg::SPLIT_IN) {
             const uint64_t twin_in = in_tile_twins(h, own, below(lane));
-            lds_st2(arr + kGB + 1u, (uint32_t)twin_in, (uint32_t)(twin_in >> 32));
+            lds_st2(arr + kGB + 2u, (uint32_t)twin_in, (uint32_t)(twin_in >> 32));
         }
         // ---- twins in the LM previous tiles (t-1 .. t-LM+1: the parser's business; t-LM: MATCH folds its visited lanes into the
         // candidates; older tiles are in the table).  If the bucket's owner -- the MOST RECENT lane with this folded hash, d tiles back --
@@ -392,8 +393,8 @@ __device__ __forceinline__ void stage_twins(uint32_t n, lds_u8_t* lds, uint32_t 
             volatile lds_u32_t* qa = recs + qslot * StageCfg::REC_WORDS + StageCfg::ARR + q * 4u;
             const u32x4_t qb = lds_ld4(qa + kGB);
             const u32x4_t qc = lds_ld4(qa + kGC);
-            const uint32_t hq = qb.w;
-            const uint64_t q_in = (uint64_t)qb.y | ((uint64_t)qb.z << 32);
+            const uint32_t hq = qb.y;
+            const uint64_t q_in = (uint64_t)qb.z | ((uint64_t)qb.w << 32);
             const uint64_t q_p1 = (uint64_t)qc.x | ((uint64_t)qc.y << 32);
             const uint64_t q_p2 = (uint64_t)qc.z | ((uint64_t)qc.w << 32);
             uint64_t q_p3 = 0;
@@ -457,7 +458,7 @@ __device__ __forceinline__ void stage_near(uint32_t n, lds_u8_t* lds, uint32_t l
         if (!stage_wait_seen(ctl, 2, t + 1u, scanned_seen, 0)) break;
         volatile lds_u32_t* rec = recs + slot * StageCfg::REC_WORDS;
         volatile lds_u32_t* arr = rec + StageCfg::ARR + lane * 4u;
-        const u32x2_t gi = lds_ld2(arr + kGB + 1u);
+        const u32x2_t gi = lds_ld2(arr + kGB + 2u);
         const u32x4_t gc = lds_ld4(arr + kGC);
         u32x2_t gd; gd.x = 0; gd.y = 0;
         if (StageCfg::LM == 4u) gd = lds_ld2(arr + kGD);
@@ -512,9 +513,9 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         const u32x4_t wv = *(volatile lds_u32x4_t*)(rec + StageCfg::W16 + lane * 4u);
         const u32x4_t gc = lds_ld4(arr + kGC);
         const u32x4_t gd = lds_ld4(arr + kGD);
-        const uint32_t h = gb.w;
+        const uint32_t h = gb.y;
         const uint4 w16 = make_uint4(wv.x, wv.y, wv.z, wv.w);
-        const uint64_t twin_in = (uint64_t)gb.y | ((uint64_t)gb.z << 32);
+        const uint64_t twin_in = (uint64_t)gb.z | ((uint64_t)gb.w << 32);
         const uint64_t twin_p1 = (uint64_t)gc.x | ((uint64_t)gc.y << 32);
         // twins in the other tiles WALK looks after (t-2 .. t-LM+1), and the mask MATCH patches with (tile t-LM)
         const uint32_t tpw_any = LM == 4u ? (gc.z | gc.w | gd.x | gd.y) : (gc.z | gc.w);
@@ -655,7 +656,7 @@ __device__ __forceinline__ void stage_commit(uint32_t n, uint16_t* table, lds_u8
         volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
         volatile lds_u32_t* arr = rec + StageCfg::ARR + lane * 4u;
         const u32x4_t gb = lds_ld4(arr + kGB);
-        const uint32_t h = gb.w, tin_lo = gb.y, tin_hi = gb.z;
+        const uint32_t h = gb.y, tin_lo = gb.z, tin_hi = gb.w;
         const uint64_t tw = __ballot((tin_lo | tin_hi) != 0u);                             // lanes with an earlier twin inside the tile
         lds_u32_t* visw = (lds_u32_t*)(rec + 2u);
         const uint64_t vis = (uint64_t)uniform(__hip_atomic_load(&visw[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) |
@@ -711,7 +712,7 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
         if (TSQ_LATE_FIX && t >= LF) {
             if (!stage_wait_seen(ctl, 2, t + 1u, scanned_seen, 6)) break;
             const u32x4_t gc = lds_ld4(arr + kGC);
-            const u32x2_t gi = lds_ld2(arr + kGB + 1u);
+            const u32x2_t gi = lds_ld2(arr + kGB + 2u);
             u32x2_t gd; gd.x = 0; gd.y = 0;
             if (LM == 4u) gd = lds_ld2(arr + kGD);
             // masks of the tiles WALK looks after, nearest first: tp[1] .. tp[LM-1]
@@ -913,7 +914,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
             auto load_record = [&]() {
                 const u32x4_t ga = lds_ld4(arr + kGA), gb = lds_ld4(arr + kGB), gc = lds_ld4(arr + kGC);      // three LDS instructions (four with LM = 4)
                 spanword = ga.x; lane_word = ga.y; orb_lo = ga.z; orb_hi = ga.w;
-                nearw = gb.x; tin_lo = gb.y; tin_hi = gb.z;
+                nearw = gb.x; tin_lo = gb.z; tin_hi = gb.w;
                 tp1_lo = gc.x; tp1_hi = gc.y; tp2r_lo = gc.z; tp2r_hi = gc.w;
                 if (LM == 4u) { const u32x2_t gd = lds_ld2(arr + kGD); tp3r_lo = gd.x; tp3r_hi = gd.y; }
                 nx = spanword >> 24;
