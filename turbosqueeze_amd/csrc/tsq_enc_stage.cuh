@@ -86,8 +86,14 @@ struct StageCfgT {
     static constexpr uint32_t W16 = 16;                           // word offset of the uint4-per-lane input words
     static constexpr uint32_t ARR = 16 + 256;                     // word offset of the per-lane words: four groups of four words per lane
     static constexpr uint32_t REC_WORDS = ARR + 16 * 64;
-    // bucket of a hash in the owner image (a multiplicative fold instead of the mask was measured: no fewer rounds in TWINS, no gain)
+    // bucket of a hash in the owner image: the top bits of a 32-bit multiplicative hash.  (Masking the 17-bit hash drops two bits that
+    // carry entropy on text: 1.6 lanes per tile met another hash in their bucket, three times what 256 live entries make likely, and
+    // every one costs TWINS a round of ballots: 44.0 -> 43.5 ms.)
+#ifdef TSQ_X_MASKFOLD
     static __device__ __forceinline__ uint32_t fold(uint32_t h) { return h & OWN_MASK; }
+#else
+    static __device__ __forceinline__ uint32_t fold(uint32_t h) { return (h * 0x9E3779B1u) >> (OWN_MASK == 0x7FFFu ? 17 : 18); }
+#endif
     static constexpr uint32_t off_owner = 0;                                   // u8[OWN_MASK + 1]
     static constexpr uint32_t off_queue = OWN_MASK + 1u;                       // u32[Q * ITEM_WORDS]
     static constexpr uint32_t off_ring = off_queue + Q * ITEM_WORDS * 4;       // u32[RING]
