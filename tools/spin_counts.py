@@ -27,7 +27,7 @@ tiles = (1 << 22) / 64
 import re
 src_ = open(os.path.join(ROOT, "turbosqueeze_amd", "csrc", "tsq_enc_stage.cuh")).read()
 mm = re.search(r"#define TSQ_X_MAP (\d+)", src_)
-pat = r"#(?:el)?if TSQ_X_MAP == %s\b[^\n]*\n\s*constexpr uint32_t role_map\[16\] = \{([^}]*)\}" % mm.group(1) if mm else r"constexpr uint32_t role_map\[16\] = \{([^}]*)\}"
+pat = r"constexpr uint32_t role_map\[16\] = \{([^}]*)\}"
 names = [x.strip().replace("kRole", "") for x in re.search(pat, src_).group(1).split(",")]
 extra = ["WALK waits for answers", "ACCOUNT waits for BUILDER (queue full)", "WALK waits for ACCOUNT (events full)", "BUILDER waits for EMIT (ring full)"]
 print(f"encode kernel {em / max(en, 1):.2f} ms; unsuccessful polls per tile, block 0:")

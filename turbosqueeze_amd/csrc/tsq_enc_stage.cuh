@@ -910,7 +910,9 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
     for (uint32_t t = 0; done == 0u; ++t, wbase = wbase + 64u == StageCfg::WIN ? 0u : wbase + 64u, rec_slot = rec_slot + 1u == StageCfg::R ? 0u : rec_slot + 1u) {
         const uint32_t base = t << 6;
         uint64_t vall = 0, Vtail = 0;
-        if (v < base + 64u) {
+        // (the walk always enters the tile: a symbol spans at most 64 positions, so v <= base - 1 + 64 here -- no test, a branch costs
+        //  the serial stage as much as five instructions whether it is taken or not)
+        {
             REG_BEGIN(0); REG_END(0);
             REG_BEGIN(1);
             // (the serial stage polls without sleeping: a wake-up from s_sleep costs it up to 64 cycles per hand-off)
