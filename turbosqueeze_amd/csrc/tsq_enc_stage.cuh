@@ -977,7 +977,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                 const uint64_t seen = vall | V;
                 const uint32_t in_lo = tin_lo & (uint32_t)seen, in_hi = tin_hi & (uint32_t)(seen >> 32);
                 uint64_t bad = __ballot((in_lo | in_hi | prev_hit) != 0u) & V;
-                if (__builtin_expect(s_nz64(V & near_m), 0)) {
+                if (__builtin_expect((V & near_m) != 0ull, 0)) {
                     // near-twin lanes (classed "no match" on the assumption that a twin at most 3 back is visited) are
                     // the other way round: they are right exactly when such a twin was visited
                     uint32_t a_lo = in_lo, a_hi = in_hi, b_lo = tp1_lo, b_hi = tp1_hi;
