@@ -794,7 +794,12 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
         }
         // (WALK also reads NEAR's word of the tile: NEAR runs tiles ahead, this wait is satisfied by what was read long ago)
         if (!stage_wait_seen(ctl, kCtlNear, t + 1u, near_seen, 6)) break;
-        lds_st4(arr + kGA, sw | (nx << 24), lw, (uint32_t)orb, (uint32_t)(orb >> 32));
+        // what WALK takes for an entry at this lane, ready to use: the lanes visited and where the walk halts (7 bits); a hard lane
+        // halts on itself with nothing visited (the serial stage then needs no select for it)
+        const bool hard_l = (sw & 0x100u) != 0u;
+        const uint32_t orb_lo = hard_l ? 0u : (uint32_t)orb, orb_hi = hard_l ? 0u : (uint32_t)(orb >> 32);
+        const uint32_t halt = hard_l ? lane : (nx & 0x7Fu);
+        lds_st4(arr + kGA, sw | (halt << 24), lw, orb_lo, orb_hi);
 #ifdef TSQ_STATS
         if (t >= 3u) { st_[24] += (uint32_t)((uint32_t)__builtin_amdgcn_s_memtime() - uniform(ctl[40u + ((t - 3u) & 7u)])); st_[25] += 1; }
 #endif
@@ -950,10 +955,9 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
             const uint32_t settled = (spanword & 0x1000u) ? 0u : 0xFFFFFFFFu;     // ORBIT has settled the lane's twins in tiles t-LF .. t-LM+1
             const uint32_t tp2_lo = LF <= 2u ? tp2r_lo & settled : tp2r_lo, tp2_hi = LF <= 2u ? tp2r_hi & settled : tp2r_hi;
             const uint32_t tp3_lo = tp3r_lo & settled, tp3_hi = tp3r_hi & settled;
-            const uint64_t hard = __ballot((spanword & 0x100u) != 0u);
             const uint64_t near_m = __ballot((spanword & 0x800u) != 0u);
             const uint64_t certain_m = __ballot((spanword & 0x400u) != 0u);
-            uint64_t Vacc = 0;                   // visited lanes not yet handed to ACCOUNT
+            uint64_t handed = 0;                 // visited lanes already handed to ACCOUNT (segments pushed in front of queries, and the query lanes)
             // a twin visited in the previous tiles: fixed for the whole tile (kept per lane, it joins the in-tile test)
             uint32_t prev_hit = (tp1_lo & (uint32_t)vall_p1) | (tp1_hi & (uint32_t)(vall_p1 >> 32)) |
                                 (tp2_lo & (uint32_t)vall_p2) | (tp2_hi & (uint32_t)(vall_p2 >> 32));
@@ -967,10 +971,10 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                 REG_BEGIN(2);
                 const uint32_t L0 = L;                                           // < 64
                 // the orbit from L0: halts on a hard lane or past the tile (nothing at all if L0 itself is hard)
-                const uint32_t o_lo = rdlane(orb_lo, L0), o_hi = rdlane(orb_hi, L0), o_nx = rdlane(nx, L0);
-                const uint32_t entry_ok = ((uint32_t)(hard >> L0) & 1u) ^ 1u;
-                uint64_t V;
-                s_sel_64_32(entry_ok, (uint64_t)o_lo | ((uint64_t)o_hi << 32), 0ull, o_nx & 0x7Fu, L0, V, L);
+                // (ORBIT's words are ready to use: a hard entry lane has an empty orbit that halts on the lane itself)
+                const uint32_t o_lo = rdlane(orb_lo, L0), o_hi = rdlane(orb_hi, L0);
+                uint64_t V = (uint64_t)o_lo | ((uint64_t)o_hi << 32);
+                L = rdlane(nx, L0);
                 // the orbit treated twin lanes as ordinary lanes.  That is wrong for a visited lane that has a VISITED
                 // twin before it (earlier in this tile, or in the two previous tiles): its gathered candidate is not
                 // current.  The first such lane ends the segment; everything before it is exact.
@@ -1001,12 +1005,11 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                     const uint64_t M = V & certain_m;
                     last_m = s_selnz64(M, base + s_msb64(M | 1ull), last_m);
                 }
-                Vacc |= V;
                 vall |= V;
                 if (L >= 64u) { v = base + L; REG_END(3); break; }
                 REG_END(3);
                 REG_BEGIN(4);
-                TSQ_CNT(26, 1); TSQ_CNT(27, ((hard >> L) & 1ull) ? 1 : 0);
+                TSQ_CNT(26, 1);
                 // ---- one hazard lane (hard, or with a visited twin): its candidate and common prefix
                 const uint32_t i = base + L;
                 uint32_t cand, k, twin_cand;
@@ -1086,9 +1089,10 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                     }
                     v = i + sp;
                     last_m = s_sel(is_m, i, last_m);
-                    Vacc |= 1ull << L;
                 } else {
-                    if (Vacc != 0ull) { ev_push(kEvSeg, base, (uint32_t)Vacc, (uint32_t)(Vacc >> 32)); Vacc = 0; }
+                    const uint64_t Vacc = vall & ~(handed | (1ull << L));
+                    if (Vacc != 0ull) ev_push(kEvSeg, base, (uint32_t)Vacc, (uint32_t)(Vacc >> 32));
+                    handed = vall;
                     ev_push(kEvHaz, i, cand, k | (twin_cand << 8));
                     n_query++;
                     TSQ_CNT(20, 1);
@@ -1108,7 +1112,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                 REG_END(5);
                 if (L >= 64u || done != 0u) break;
             }
-            Vtail = Vacc;
+            Vtail = vall & ~handed;
         }
         // ---- the tile's last segment goes to ACCOUNT, its visited mask to MATCH and COMMIT (they patch / commit the table), and the
         //      tile counter moves on: four stores of lane 0 in one stretch (the LDS executes them in this order)
