@@ -40,8 +40,8 @@
 // WALK looks after the twins of tiles t-LM+1 .. t.  LM = 3, LF = 2 was round 3's pipeline: the loops WALK(t-3) -> MATCH(t) -> ORBIT(t) ->
 // WALK(t) and WALK(t-2) -> ORBIT(t) -> WALK(t) paced it together with the serial stage itself.  With LM = 4, LF = 3 (standard layout)
 // neither loop is ever waited for (tools/bottleneck.sh: MATCH, ORBIT, COMMIT at 0.01 - 0.04), at the price of 0.18 more hazard lanes
-// per tile for WALK; what paces the pipeline then is the busiest wavefront.  The lean layout (two blocks per CU hide each other's
-// waits) keeps LM = 3, LF = 2: measured 33.0 GB/s against 29.0 at 1 024 blocks.
+// per tile for WALK; what paces the pipeline then is the busiest wavefront -- WALK itself.  The lean layout (two blocks per CU hide each
+// other's waits) gains little from it: 4 GiB of text 34.4 GB/s either way without extensions, 32.7 against 31.4 with them.
 #ifndef TSQ_LM
 #define TSQ_LM 4
 #endif
@@ -49,10 +49,10 @@
 #define TSQ_LF 3
 #endif
 #ifndef TSQ_LM_LEAN
-#define TSQ_LM_LEAN 3
+#define TSQ_LM_LEAN 4
 #endif
 #ifndef TSQ_LF_LEAN
-#define TSQ_LF_LEAN 2
+#define TSQ_LF_LEAN 3
 #endif
 
 #include "tsq_common.cuh"
