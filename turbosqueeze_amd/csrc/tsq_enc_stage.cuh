@@ -966,8 +966,10 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
             const uint32_t cand0 = lane_word & 0xFFFFFFu;
 
             uint32_t L = v - base;
-            REG_END(1);
-            for (;;) {
+            // One segment: the orbit from lane L and the first lane on it whose candidate is stale; sets L to that lane (a hazard lane) or
+            // to where the walk leaves the tile.  The first segment of a tile is straight-line code: two tiles out of three end with it,
+            // and every loop exit costs the serial stage a branch or two.
+            auto segment = [&]() {
                 REG_BEGIN(2);
                 const uint32_t L0 = L;                                           // < 64
                 // the orbit from L0: halts on a hard lane or past the tile (nothing at all if L0 itself is hard)
@@ -1006,7 +1008,9 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                     last_m = s_selnz64(M, base + s_msb64(M | 1ull), last_m);
                 }
                 vall |= V;
-                if (L >= 64u) { v = base + L; REG_END(3); break; }
+                v = base + L;
+            };
+            auto hazard_lane = [&]() {
                 REG_END(3);
                 REG_BEGIN(4);
                 TSQ_CNT(26, 1);
@@ -1110,7 +1114,12 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                 }
                 L = v - base;
                 REG_END(5);
+            };
+            segment();
+            while (L < 64u) {
+                hazard_lane();
                 if (L >= 64u || done != 0u) break;
+                segment();
             }
             Vtail = vall & ~handed;
         }
