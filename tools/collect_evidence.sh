@@ -34,11 +34,17 @@ PY
 ) > $OUT/traffic_experiment_pmc.log 2>&1
 timeout 300 python tools/quick_check.py > $OUT/quick_check.txt 2>&1
 for n in 1073741824 4294967296; do timeout 300 python tools/config5_sweep.py $n 1 2>/dev/null; done > $OUT/config5.jsonl
-timeout 300 python tools/config5_sweep.py 1342177280 0 0 text 2>/dev/null >> $OUT/config5.jsonl
+# more blocks than CUs with a partial last round: 1.25 GiB + 4 KiB of text = 321 blocks (256 + 65), and one GPU's share of config 5 at N = 8:
+# 320 blocks of the 50 % mix with extensions (256 + 64)
+timeout 300 python tools/config5_sweep.py 1342181376 0 0 text 2>/dev/null >> $OUT/config5.jsonl
+timeout 300 python tools/config5_sweep.py 1342177280 1 0 mix 2>/dev/null >> $OUT/config5.jsonl
+timeout 300 python tools/config5_sweep.py 4294967296 0 0 text 2>/dev/null >> $OUT/config5.jsonl
 for args in "--synthetic 1000000000 --reps 5 --no-ext" "--synthetic 1000000000 --reps 5" "--synthetic 4000000000 --reps 3"; do timeout 300 tools/tsq_cli b $args 2>/dev/null | tail -1; done > $OUT/cli_host_buffers.json
 tools/micro/lds_unaligned > $OUT/lds_access_costs.txt 2>&1
 TSQ_BENCH_BACKEND=gloo TSQ_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --steps 5 --warmup 2 --no-weak 2>/dev/null | tail -1 > $OUT/bench_2ranks_1gpu.json
 (TSQ_AMD_DEBUG=1 timeout 200 tools/tsq_cli b --synthetic 1000000000 --reps 2 --no-ext 2>&1 | tail -45) > $OUT/cli_timeline.txt
 mkdir -p gpurun_out/x; bash tools/bottleneck.sh run > $OUT/bottleneck.txt 2>&1
 python tools/spin_counts.py > $OUT/spin_counts.txt 2>&1
+bash tools/sq_counters.sh $TAG > gpurun_out/${TAG}_sq.log 2>&1
+bash tools/sq_units.sh > $OUT/sq_units.txt 2>&1
 ls -la $OUT

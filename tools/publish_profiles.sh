@@ -22,4 +22,5 @@ cp $S/bottleneck.txt profiles/${TAG}_encoder_bottleneck.txt
 cp $S/spin_counts.txt profiles/${TAG}_encoder_spin_counts.txt
 [ -f gpurun_out/${TAG}_sq.log ] && grep -v amdgpu.ids gpurun_out/${TAG}_sq.log > profiles/${TAG}_sq_counters.txt
 [ -f $S/regions.txt ] && cp $S/regions.txt profiles/${TAG}_walk_regions.txt
+[ -f $S/sq_units.txt ] && grep -v amdgpu.ids $S/sq_units.txt > profiles/${TAG}_sq_units.txt
 ls -la profiles/${TAG}_*

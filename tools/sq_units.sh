@@ -1,5 +1,7 @@
 #!/bin/bash
-OUT=gpurun_out/sq2; mkdir -p $OUT
+# Per-unit busy counters of the dominant kernels (VALU / scalar / LDS active cycles, LDS conflicts and misaligned accesses): separate
+# rocprofv3 passes of two counters each, kernel-trace only.  Usage (GPU box, repo root): bash tools/sq_units.sh
+OUT=gpurun_out/sq_units; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 for pair in "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" "SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT" "SQ_INSTS_LDS SQ_LDS_UNALIGNED_STALL" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_MISC"; do
   name=$(echo $pair | tr ' ' '_')

@@ -1009,9 +1009,9 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                 }
                 vall |= V;
                 v = base + L;
+                REG_END(3);
             };
             auto hazard_lane = [&]() {
-                REG_END(3);
                 REG_BEGIN(4);
                 TSQ_CNT(26, 1);
                 // ---- one hazard lane (hard, or with a visited twin): its candidate and common prefix
