@@ -198,7 +198,7 @@ int tsqa_measure_copy(tsqa_ctx *ctx, size_t bytes, int reps, double *best_gbps, 
 /* which launch shape the last tsqa_measure_copy on this context chose (text; "" before the first probe) */
 const char *tsqa_copy_probe_shape(const tsqa_ctx *ctx);
 
-/* Kernel variant selection.  Encoder: 0 = default (twelve-wave staged encoder; its lean layout by itself when there are
+/* Kernel variant selection.  Encoder: 0 = default (staged encoder, one workgroup of fourteen working wavefronts per block; its lean layout -- twelve -- by itself when there are
  * more blocks than CUs), 1 = serial kernel (one lane walks the block; correctness baseline), 6 = force the lean layout
  * (two blocks per CU), 7 = never lean.  Decoder: 0 = default (byte-lane decoder; on two workgroups per block when a
  * launch has at most half as many blocks as the device has CUs, three -- two of them parsing alternate windows of the stream --

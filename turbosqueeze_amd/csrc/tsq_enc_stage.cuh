@@ -1,33 +1,33 @@
-// tsq_enc_stage.cuh -- staged block encoder for gfx950: twelve wavefronts per block (kernel variant 0).
+// tsq_enc_stage.cuh -- staged block encoder for gfx950: fourteen working wavefronts per block, twelve in the lean layout (kernel variant 0).
 //
 // A single wavefront issues about one instruction every five cycles, and the greedy parse of a block is
 // serial (tsq_encode.cpp:72-187: the position table is a function of the parse).  So the block's work
 // is cut into stages that stream 64-position tiles through records in LDS; the serial stage is kept as
 // small as it can be and everything else is spread over as many wavefronts as it takes to keep up with it:
 //
-//   HASH     input words (next tile prefetched), hashes, the "owner image" (one byte per folded hash bucket:
-//            which lane of the last three tiles wrote it last) -- a filter for equal hashes.
-//   TWINS    the exact same-hash ("twin") masks of every lane against the earlier lanes of its tile and the
-//            three tiles before: inherited from the bucket owner's own masks when the owner has the lane's
-//            hash (no search), settled with ballots on a fold collision.
+//   HASH     input words (requested four tiles ahead), hashes, the "owner image" (one byte per bucket of a multiplicative fold of
+//            the hash: which lane of the last four tiles wrote it last) -- a filter for equal hashes.
+//   IN       the twins inside the tile: for every lane the earlier lanes with its hash (one round of ballots per group).
+//   TWINS    the exact same-hash ("twin") masks of every lane against the LM tiles before: inherited from the bucket
+//            owner's own masks when the owner has the lane's hash (no search), settled with ballots on a fold collision.
 //   NEAR     the common prefix of every lane with its nearest twin, ahead of time (WALK's hazard lanes mostly need exactly that).
 //   MATCH x2 (even / odd tiles) the candidates: gather from the position table, patch with the visited twins
-//            of tile t-3 (mask test), candidate bytes from the input window ring in LDS, common prefix,
+//            of tile t-LM (mask test), candidate bytes from the input window ring in LDS, common prefix,
 //            lane classes (certain match / certain literal / hazard).
 //   ORBIT x2 (even / odd tiles) the visited set from every possible entry lane of the tile, by pointer doubling;
-//            first the late classification of lanes whose only twins are in tile t-2.
+//            first the late classification of lanes whose only twins are LF or more tiles back.
 //   WALK     THE serial stage: picks the orbit of the actual entry lane, checks the twins it visited, finds a
 //            hazard lane's candidate; decides it on the spot when no pair origin can matter, else asks ACCOUNT.
 //   ACCOUNT  the symbol state (count, pair origin, pending literal) in O(1) per tile from WALK's masks, the exact
 //            scalar decision of the hazards WALK could not decide, the items for the builder.
 //   COMMIT   the position table's writer: the visited positions of a tile, as soon as WALK has published them.
-//   BUILDER  symbol records from the items (tsq_enc_builder.cuh: stream_builder).
+//   BUILDER x2 (items alternately) symbol records from the items (tsq_enc_builder.cuh: stream_builder).
 //   EMIT     stream layout, 64 symbols at a time (tsq_enc_builder.cuh: stream_emitter).
 //
-// Table lag.  MATCH gathers tile t from a table that holds the visits of tiles <= t-4 (COMMIT publishes how far it
-// is) and patches in the visits of tile t-3 from TWINS' masks, so WALK and MATCH overlap over two tiles.  What the
-// table cannot know -- a visited position of tiles t-2, t-1 or an earlier lane of t with the same hash -- is a
-// twin: TWINS finds all of them exactly, and WALK takes the most recent VISITED twin as the candidate, which is
+// Table lag.  MATCH gathers tile t from a table that holds the visits of tiles <= t-LM-1 (COMMIT publishes how far it
+// is) and patches in the visits of tile t-LM from TWINS' masks, so WALK and MATCH overlap over LM-1 tiles.  What the
+// table cannot know -- a visited position of tiles t-LM+1 .. t-1 or an earlier lane of t with the same hash -- is a
+// twin: TWINS and IN find all of them exactly, and WALK takes the most recent VISITED twin as the candidate, which is
 // what the reference's table would hold (tsq_encode.cpp:76-79), or keeps the gathered candidate when no twin
 // was visited.  The output therefore does not depend on how the wavefronts interleave (make jitter: a stress
 // build that delays every hand-off pseudo-randomly; tests/test_gpu_parity.py::test_encoder_handoffs_under_jitter).
@@ -108,7 +108,7 @@ struct StageCfgT {
 //            5 tiles walked, 6 stop, 7..9 BUILDER/EMIT (tsq_enc_builder.cuh), 10..14 WALK/ACCOUNT events, 33 tiles committed, 34 tiles hashed,
 // record: header words 2,3 = the lanes the parse visited (WALK)
 //         per-lane words, in four groups of four: group g of lane l is the 16-byte LDS word at ARR + g * 256 + l * 4, so that a stage
-//         reads or writes a whole group (or half of one) with ONE LDS instruction -- the LDS pipe is what the twelve wavefronts share,
+//         reads or writes a whole group (or half of one) with ONE LDS instruction -- the LDS pipe is what all the wavefronts share,
 //         and a 4-byte access per lane costs it as much as an 8-byte one and half of a 16-byte one:
 //           A: spanword | candidate | nibble << 24 | orbit mask lo, hi                 (MATCH, ORBIT -> WALK, ACCOUNT)
 //           B: owner word (HASH -> TWINS), then the nearest twin's word (NEAR) | hash | twins in this tile (earlier lanes) lo, hi
@@ -1433,11 +1433,11 @@ __global__ __launch_bounds__(1024) void enc_stage_kernel(const uint8_t* __restri
     const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u;
     // Wave w of a workgroup runs on SIMD w % 4 (read back from HW_ID in the instrumented build).  WALK, the serial stage, gets a SIMD
     // almost to itself (NEAR, a light stage, shares it): the two other wavefronts of SIMD 0 leave right after the prologue.
-    //   SIMD 0: WALK, NEAR      SIMD 1: ORBIT even, MATCH even, HASH, BUILDER     SIMD 2: ORBIT odd, MATCH odd, TWINS, EMIT     SIMD 3: ACCOUNT, COMMIT
+    //   SIMD 0: WALK, NEAR      SIMD 1: ORBIT even, MATCH even, HASH, BUILDER     SIMD 2: ORBIT odd, MATCH odd, TWINS, EMIT     SIMD 3: ACCOUNT, COMMIT, IN, BUILDER 2
     // (measured: ACCOUNT next to WALK on SIMD 0 costs 8 to 13 ms -- WALK polls without sleeping and starves the wavefront whose
     //  answers it waits for; a third ORBIT wavefront +1.4 ms; s_setprio, COMMIT / EMIT / HASH on SIMD 0, NEAR on SIMD 2 or 3: within 0.3 %)
     enum : uint32_t { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNone, kRoleMatch0, kRoleMatch1, kRoleBuilder, kRoleHash, kRoleTwins, kRoleEmit, kRoleCommit, kRoleNear, kRoleIn, kRoleBuilder1 };
-    // (the lean layout -- two workgroups per CU -- launches the twelve working wavefronts only: 2 x 16 do not fit a CU's wave slots)
+    // (the lean layout -- two workgroups per CU -- launches its twelve working wavefronts only: 2 x 13 already do not fit a CU's wave slots)
     constexpr uint32_t role_map[16] = { kRoleWalk, kRoleOrbit0, kRoleOrbit1, kRoleAccount, kRoleNear, kRoleMatch0, kRoleMatch1, kRoleCommit,
                                         kRoleNone, kRoleHash, kRoleTwins, kRoleIn, kRoleNone, kRoleBuilder, kRoleEmit, kRoleBuilder1 };
     // (lean layout, measured at 4 GiB: this placement 30.7 GB/s on text against 29.4 for the round's earlier one)

@@ -1,6 +1,6 @@
 // tsq_launch.cuh -- kernel selection and launch for the device context.
 //
-// The product library carries three kernel families: the twelve-wave staged encoder (tsq_enc_stage.cuh, standard and lean
+// The product library carries three kernel families: the staged encoder (tsq_enc_stage.cuh: fourteen working wavefronts per block, twelve in the lean layout; standard and lean
 // layouts, with and without extensions), the byte-lane decoder (tsq_dec_sym.cuh, tsq_dec_duo.cuh) and the serial correctness
 // baselines (tsq_serial.cuh, variant 1).  The previous round's production encoder (ab/tsq_enc_stage_r03.cuh, encoder variant 5) is
 // compiled only into the A/B library (`make ab`, -DTSQ_AB_VARIANTS), which tests/test_gpu_parity.py holds against the same oracle.
@@ -77,7 +77,7 @@ inline int launch_encode_kernels(tsqa_ctx* c, const uint8_t* in, size_t n, size_
     if (v == 5) { c->set_error("kernel variant %d lives in the A/B library only (make ab)", v); return TSQA_ERR_ARG; }
 #endif
     if (v >= 2 && v <= 4) { c->set_error("kernel variant %d is not built", v); return TSQA_ERR_ARG; }
-    // twelve-wave staged pipeline (tsq_enc_stage.cuh).  More blocks than CUs: the lean layout (no input window in LDS, candidate
+    // staged pipeline (tsq_enc_stage.cuh).  More blocks than CUs: the lean layout (no input window in LDS, candidate
     // bytes from L2) lets several blocks share a CU; each is a little slower, together they are faster.
     const bool lean = v == 6 || (v == 0 && nb > (uint32_t)c->n_cus);
     if (lean) {
