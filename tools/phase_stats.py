@@ -37,14 +37,13 @@ T = max(e[15], 1)
 print(f"ENC staged pipeline block0 (tiles parsed={e[15]}, symbols={e[16]}); cycles per tile, busy = total - waited:")
 print("  HASH    total=%.0f waited(ring)=%.0f busy=%.0f" % (e[1] / T, e[0] / T, (e[1] - e[0]) / T))
 print("  TWINS   total=%.0f waited(hash)=%.0f busy=%.0f" % (e[49] / T, e[48] / T, (e[49] - e[48]) / T))
-print("          unsure lanes per tile=%.2f, settle rounds per tile=%.2f, in-tile group rounds per tile=%.2f" % (e[32] / T, e[33] / T, e[34] / T))
+print("          lanes behind a fold collision per tile=%.2f, settle rounds per tile=%.2f" % (e[32] / T, e[33] / T))
+print("  IN      total=%.0f waited(hash)=%.0f busy=%.0f" % (e[58] / T, e[57] / T, (e[58] - e[57]) / T))
 print("  MATCH   total=%.0f waited(scan)=%.0f waited(parser)=%.0f busy=%.0f" % (e[4] / T, e[2] / T, e[3] / T, (e[4] - e[2] - e[3]) / T))
 print("          length-extension rounds per tile=%.2f (from the window ring %.2f), tiles classified twice (even wave)=%.3f" % (e[36] / T, e[35] / T, e[50] / T))
 print("  COMMIT  total=%.0f waited=%.0f busy=%.0f" % (e[46] / T, e[45] / T, (e[46] - e[45]) / T))
 print("  ORBIT   total=%.0f waited=%.0f busy=%.0f" % (e[7] / T, e[6] / T, (e[7] - e[6]) / T))
-print("  lag loop (even tiles): WALK publishes tile t-3 -> MATCH publishes tile t: %.0f cycles -> ORBIT publishes tile t: %.0f cycles" % (e[51] / max(e[52], 1), e[53] / max(e[54], 1)))
 print("  WALK    total=%.0f waited(orbit)=%.0f waited(events)=%.0f waited(answers)=%.0f busy=%.0f  queries per tile=%.3f" % (e[10] / T, e[8] / T, e[9] / T, e[40] / T, (e[10] - e[8] - e[9] - e[40]) / T, e[20] / T))
-print("          short way through the tile: %.3f of the tiles; ORBIT: tiles with a late classification %.3f, orbits computed again %.3f" % (e[59] / T, 2 * e[57] / T, 2 * e[58] / T))
 print("  ACCOUNT total=%.0f waited(events)=%.0f waited(queue)=%.0f busy=%.0f  tiles with events=%.3f" % (e[43] / T, e[41] / T, e[42] / T, (e[43] - e[41] - e[42]) / T, e[44] / T))
 
 print("  BUILDER total=%.0f waited=%.0f (ring %.0f) busy=%.0f" % (e[18] / T, e[17] / T, e[37] / T, (e[18] - e[17]) / T))
