@@ -48,7 +48,11 @@ enum {
     TSQA_ERR_ARG       = 3,   /* null pointer, zero size, capacity too small */
     TSQA_ERR_FORMAT    = 4,   /* bad magic, n_blocks == 0, frame size 0 or > TSQ_OUTPUT_SZ, truncated */
     TSQA_ERR_STREAM    = 5,   /* a block stream is malformed (bad offset, overrun) */
-    TSQA_ERR_OVERFLOW  = 6    /* a block expanded beyond TSQ_OUTPUT_SZ */
+    TSQA_ERR_OVERFLOW  = 6,   /* a block expanded beyond TSQ_OUTPUT_SZ */
+    TSQA_ERR_STALL     = 7    /* a decode on several workgroups per block gave up waiting for a sibling workgroup (the GPU was busy
+                                 with other work for seconds): the container may be fine.  The synchronous entry points and the
+                                 reference-named API decode again on one workgroup per block by themselves; the stream-ordered
+                                 (*_async) entry points report it in *d_status -- decode again with decode variant 4 */
 };
 
 /* =====================================================================================
@@ -206,6 +210,9 @@ const char *tsqa_copy_probe_shape(const tsqa_ctx *ctx);
  * CUs allow), 4 = always one, 5 = always three, 6 = always two.  The previous round's production encoder (encoder 5) exists only in the A/B library
  * built by `make ab`; the product library rejects it. */
 void tsqa_set_kernel_variant(tsqa_ctx *ctx, int encode_variant, int decode_variant);
+/* How many polls (of ~0.1 us) a decode on several workgroups per block waits for a sibling workgroup before it reports
+ * TSQA_ERR_STALL (default 2^24: seconds).  Tests set it to 1 to exercise the retry. */
+void tsqa_set_decode_wait_limit(tsqa_ctx *ctx, uint32_t polls);
 
 /* =====================================================================================
  * (1) The reference API (turbosqueeze.h:441-674), C-callable subset

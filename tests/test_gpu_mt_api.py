@@ -266,3 +266,16 @@ def test_cli_tool(tsq, oracle, tmp_path):                  # sample/main.cpp: `t
                        timeout=300, capture_output=True, text=True)
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["output_correct"] is True and line["input_bytes"] == 3 * (1 << 22) + 5
+
+
+def test_decode_stall_is_retried_by_the_mt_api(tsq, oracle, monkeypatch):
+    """tsqDecompress_MT and tsqDecode decode on several workgroups per block when a batch has few blocks; a workgroup that gives up
+    waiting for a sibling (TSQA_ERR_STALL -- forced here with a wait limit of one poll) must not turn a good container into a
+    failure: the scheduler decodes the batch again on one workgroup per block."""
+    monkeypatch.setenv("TSQ_AMD_DECODE_WAIT_LIMIT", "1")
+    host = tsq.synth.text(9 * (1 << 22) + 777, seed=93)
+    data = host.tobytes()
+    blob = oracle.compress(host, 0, threads=4)
+    assert tsq.tsq_decompress_mt(blob) == data
+    small = data[:300_000]
+    assert tsq.tsq_decode(oracle.encode_block(small, 1), 1) == small

@@ -533,3 +533,31 @@ def test_bench_sharded_path_over_rccl_with_one_rank(tsq):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["config"]["container_equals_oracle"] is True and line["config"]["collective_backend"] == "nccl"
     assert line["rank0_step_breakdown_ms"]["size_gather"] > 0
+
+
+def test_decode_stall_is_not_a_stream_error_and_is_retried(tsq, oracle):
+    """A decode on several workgroups per block waits for sibling workgroups; when one does not show up within the wait limit the
+    kernel reports TSQA_ERR_STALL (7), not a malformed stream.  With the limit set to one poll the waits give up at
+    once: the stream-ordered entry point must report 7, and the synchronous one must decode again on one workgroup per block by
+    itself and return the right bytes."""
+    import torch
+    B = 1 << 22
+    host = tsq.synth.text(12 * B + 12345, seed=91)
+    src = to_dev(host)
+    c = tsq.DeviceCodec(0)
+    try:
+        blob = c.compress(src, 0).clone()
+        assert bytes(blob.cpu().numpy()) == oracle.compress(host, 0, threads=4)
+        c.set_variant(0, 5)                                  # always three workgroups per block
+        c.set_decode_wait_limit(1)
+        back = torch.zeros(src.numel(), dtype=torch.uint8, device="cuda")
+        c.decompress_async(blob, 13, back)
+        torch.cuda.synchronize()
+        _, status = c.last_size_status()
+        assert status == 7, status                           # TSQA_ERR_STALL: nothing wrong with the container
+        out = c.decompress(blob)                             # synchronous: decodes again on one workgroup per block
+        assert torch.equal(out, src)
+        c.set_decode_wait_limit(1 << 24)
+        assert torch.equal(c.decompress(blob), src)          # and the three-workgroup decode itself is fine with the normal limit
+    finally:
+        c.close()

@@ -96,6 +96,8 @@ def lib(ab=False) -> C.CDLL:
     L.tsqa_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     L.tsqa_set_kernel_variant.restype = None
     L.tsqa_set_kernel_variant.argtypes = [vp, C.c_int, C.c_int]
+    L.tsqa_set_decode_wait_limit.restype = None
+    L.tsqa_set_decode_wait_limit.argtypes = [vp, C.c_uint32]
     # reference API
     L.tsqAllocateContext.restype = vp
     L.tsqDeallocateContext.argtypes = [vp]
@@ -197,6 +199,10 @@ class DeviceCodec:
 
     def set_variant(self, enc: int, dec: int) -> None:
         self.L.tsqa_set_kernel_variant(self.h, enc, dec)
+
+    def set_decode_wait_limit(self, polls: int) -> None:
+        """polls a several-workgroups-per-block decode waits for a sibling workgroup before it reports TSQA_ERR_STALL"""
+        self.L.tsqa_set_decode_wait_limit(self.h, polls)
 
     def profile(self, on: bool) -> None:
         self.L.tsqa_profile_enable(self.h, 1 if on else 0)

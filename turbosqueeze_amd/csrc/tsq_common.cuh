@@ -16,7 +16,7 @@ constexpr uint32_t kHashMask    = kHashEntries - 1u;
 constexpr uint32_t kWave        = 64;
 
 // status codes mirrored from include/turbosqueeze_amd.h
-constexpr int32_t kOk = 0, kErrFormat = 4, kErrStream = 5, kErrOverflow = 6;
+constexpr int32_t kOk = 0, kErrFormat = 4, kErrStream = 5, kErrOverflow = 6, kErrStall = 7;
 
 // Per-block frame description produced by the frame-walk kernel for the decoders.
 struct FrameInfo {

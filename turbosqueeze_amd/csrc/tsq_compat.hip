@@ -634,7 +634,22 @@ private:
             Lane& l = lanes_[f.lane];
             if (!issued_[f.lane]->wait()) { ok = false; return; }     // the lane's feeder has issued the batch (or failed to)
             (void)hipSetDevice(l.dev->device);
-            if (hipEventSynchronize(l.ev) != hipSuccess || *l.h_status != 0) { ok = false; return; }
+            if (hipEventSynchronize(l.ev) != hipSuccess) { ok = false; return; }
+            if (*l.h_status == tsq::kErrStall) {
+                // a sibling workgroup of a several-workgroups-per-block decode did not get onto the GPU in time: the batch is still on
+                // the device -- once more with one workgroup per block
+                hipStream_t s = l.dev->stream;
+                const int keep = l.dev->dec_variant;
+                l.dev->dec_variant = 4;
+                bool good = hipMemsetAsync(l.dev->d_status, 0, sizeof(int32_t), s) == hipSuccess;
+                good = good && l.dev->launch_decode(l.d_in, f.n_blocks, l.d_out, l.dev->d_status, s) == TSQA_OK;
+                l.dev->dec_variant = keep;
+                good = good && hipMemcpyAsync(l.h_status, l.dev->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s) == hipSuccess;
+                good = good && hipStreamSynchronize(s) == hipSuccess;
+                mk.at("decompress: batch decoded again (stall)");
+                if (!good) { ok = false; return; }
+            }
+            if (*l.h_status != 0) { ok = false; return; }
             mk.at("decompress: kernels done");
             // the blocks come back in pieces of a few blocks, in order; each block reports progress once it has landed
             // (tsq_threads.cpp:648-655: the writer copies a block out, then calls progress_cb)
@@ -931,9 +946,21 @@ extern "C" void tsqDecode(uint8_t* inputBlock, uint8_t* outputBlock, uint32_t* o
     (void)hipMemcpyAsync(l.dev->frames, l.h_frames, sizeof(FrameInfo), hipMemcpyHostToDevice, s);
     (void)hipMemsetAsync(l.dev->d_status, 0, sizeof(int32_t), s);
     if (l.dev->launch_decode(l.d_in, 1, l.d_out, l.dev->d_status, s) != TSQA_OK) return;
-    (void)hipMemcpyAsync(l.h_out, l.d_out, usize, hipMemcpyDeviceToHost, s);
     (void)hipMemcpyAsync(l.h_status, l.dev->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s);
-    if (hipStreamSynchronize(s) != hipSuccess || *l.h_status != 0) return;
+    if (hipStreamSynchronize(s) != hipSuccess) return;
+    if (*l.h_status == tsq::kErrStall) {          // (a sibling workgroup did not get onto the GPU in time: once more on one workgroup)
+        const int keep = l.dev->dec_variant;
+        l.dev->dec_variant = 4;
+        (void)hipMemsetAsync(l.dev->d_status, 0, sizeof(int32_t), s);
+        const int rc = l.dev->launch_decode(l.d_in, 1, l.d_out, l.dev->d_status, s);
+        l.dev->dec_variant = keep;
+        if (rc != TSQA_OK) return;
+        (void)hipMemcpyAsync(l.h_status, l.dev->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) return;
+    }
+    if (*l.h_status != 0) return;
+    (void)hipMemcpyAsync(l.h_out, l.d_out, usize, hipMemcpyDeviceToHost, s);
+    if (hipStreamSynchronize(s) != hipSuccess) return;
     memcpy(outputBlock, l.h_out, usize);
     *outputSize = usize;
 }

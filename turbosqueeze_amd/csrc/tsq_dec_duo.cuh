@@ -32,7 +32,8 @@ struct DuoCfg {
                                                                            // [8 + 8 p ..]: the entry mailbox of PARSE workgroup p (sequence, delta | flags << 16, op, record)
     static constexpr uint32_t kLast = 1, kError = 2;
     static constexpr uint32_t kAbort = 0xFFFFFFFFu;
-    static constexpr uint32_t kSpinLimit = 1u << 24;                       // polls (with s_sleep) before a wait gives up: seconds
+    static constexpr uint32_t kSpinLimit = 1u << 24;                       // default number of polls (with s_sleep) before a wait gives up: seconds
+                                                                           // (the launch passes the context's limit: tsqa_set_decode_wait_limit)
 };
 
 // polls are relaxed loads (an acquire load invalidates the CU's vector cache every time: hundreds of polling workgroups would keep
@@ -51,7 +52,8 @@ __device__ __forceinline__ void duo_store_release(uint32_t* p, uint32_t v) { __h
 // NP = 1: the same code, the entry is handed over in registers.
 template <uint32_t NP>
 __device__ __forceinline__ void duo_parse(const uint8_t* __restrict__ in, uint32_t in_len, uint32_t size, uint32_t ext, uint32_t me,
-                                          uint32_t* __restrict__ ring_g, uint32_t* __restrict__ flags, int32_t* __restrict__ status, uint8_t* lds)
+                                          uint32_t* __restrict__ ring_g, uint32_t* __restrict__ flags, int32_t* __restrict__ status, uint8_t* lds,
+                                          uint32_t spin_limit)
 {
     using C = SymCfg;
     uint8_t* const s_raw = lds + SymLds::sbuf;
@@ -93,7 +95,7 @@ __device__ __forceinline__ void duo_parse(const uint8_t* __restrict__ in, uint32
     auto give_up = [&](uint32_t why) {
         // (uniform: every thread calls it) tell the others and leave
         if (tid == 0) {
-            if (why == 2u) atomicMax(status, kErrStream);
+            if (why == 2u) atomicMax(status, kErrStall);       // (a sibling workgroup did not show up in time: not the stream's fault)
             duo_store_release(flags + 32, DuoCfg::kAbort);
         }
     };
@@ -162,7 +164,7 @@ __device__ __forceinline__ void duo_parse(const uint8_t* __restrict__ in, uint32
                 for (;;) {
                     if (duo_load_acquire(entry_in) > n_in) break;
                     if ((spins & 63u) == 63u && (duo_load_acquire(flags + 32) == DuoCfg::kAbort || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { why = 1; break; }
-                    if (++spins > DuoCfg::kSpinLimit) { why = 2; break; }
+                    if (++spins > spin_limit) { why = 2; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 duo_acquire_fence();
@@ -269,7 +271,7 @@ __device__ __forceinline__ void duo_parse(const uint8_t* __restrict__ in, uint32
                     const uint32_t done = duo_load_acquire(flags + 32);
                     if (done == DuoCfg::kAbort || ((spins & 255u) == 255u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { why = 1; break; }
                     if (rec_no - done < DuoCfg::SLOTS && (NP == 1u || duo_load_acquire(flags) == rec_no)) break;
-                    if (++spins > DuoCfg::kSpinLimit) { why = 2; break; }
+                    if (++spins > spin_limit) { why = 2; break; }
                     __builtin_amdgcn_s_sleep(8);                                   // (nobody waits for this workgroup while its ring is full)
                 }
                 duo_acquire_fence();
@@ -317,7 +319,8 @@ struct DuoCopyLds {
 static_assert(DuoCopyLds::total <= 160 * 1024 && SymLds::total <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ void duo_copy(const uint8_t* __restrict__ in, uint32_t in_len, uint32_t size, uint32_t ext, uint8_t* __restrict__ out,
-                                         const uint32_t* __restrict__ ring_g, uint32_t* __restrict__ flags, int32_t* __restrict__ status, uint8_t* lds)
+                                         const uint32_t* __restrict__ ring_g, uint32_t* __restrict__ flags, int32_t* __restrict__ status, uint8_t* lds,
+                                         uint32_t spin_limit)
 {
     using C = SymCfg;
     uint8_t* const sbuf = lds + DuoCopyLds::sbuf;
@@ -374,7 +377,7 @@ __device__ __forceinline__ void duo_copy(const uint8_t* __restrict__ in, uint32_
                     made = duo_load_acquire(flags);
                     if (made > k) break;
                     if ((spins & 255u) == 255u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { give_up = 1; break; }
-                    if (++spins > DuoCfg::kSpinLimit) { give_up = 2; break; }
+                    if (++spins > spin_limit) { give_up = 2; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 duo_acquire_fence();
@@ -382,7 +385,7 @@ __device__ __forceinline__ void duo_copy(const uint8_t* __restrict__ in, uint32_
             }
             __syncthreads();
             if (misc[6] != 0) {
-                if (tid == 0) { duo_store_release(flags + 32, DuoCfg::kAbort); if (misc[6] == 2) atomicMax(status, kErrStream); }
+                if (tid == 0) { duo_store_release(flags + 32, DuoCfg::kAbort); if (misc[6] == 2) atomicMax(status, kErrStall); }
                 return;
             }
             made_seen = misc[7];
@@ -609,7 +612,7 @@ __device__ __forceinline__ void duo_copy(const uint8_t* __restrict__ in, uint32_
 template <uint32_t NP>
 __global__ __launch_bounds__(1024) void dec_duo_kernel(const uint8_t* __restrict__ container, const FrameInfo* __restrict__ frames, uint32_t n_blocks,
                                                        uint8_t* __restrict__ outbuf, int32_t* __restrict__ status,
-                                                       uint32_t* __restrict__ ring_g, uint32_t* __restrict__ flags_g)
+                                                       uint32_t* __restrict__ ring_g, uint32_t* __restrict__ flags_g, uint32_t spin_limit)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t w = blockIdx.x, xcd = w & 7u, slot = w >> 3;
@@ -634,8 +637,8 @@ __global__ __launch_bounds__(1024) void dec_duo_kernel(const uint8_t* __restrict
     }
     uint32_t* const ring_b = ring_g + (size_t)b * DuoCfg::SLOTS * DuoCfg::REC_WORDS;
     uint32_t* const flags = flags_g + (size_t)b * DuoCfg::FLAG_STRIDE;
-    if (role < NP) duo_parse<NP>(container + f.stream_at, f.stream_len, f.out_len, f.ext, role, ring_b, flags, status, lds);
-    else duo_copy(container + f.stream_at, f.stream_len, f.out_len, f.ext, outbuf + f.out_at, ring_b, flags, status, lds);
+    if (role < NP) duo_parse<NP>(container + f.stream_at, f.stream_len, f.out_len, f.ext, role, ring_b, flags, status, lds, spin_limit);
+    else duo_copy(container + f.stream_at, f.stream_len, f.out_len, f.ext, outbuf + f.out_at, ring_b, flags, status, lds, spin_limit);
 }
 
 }  // namespace tsq

@@ -34,6 +34,7 @@ struct tsqa_ctx {
     uint64_t* d_size = nullptr;        // result words of the synchronous entry points
     int32_t* d_status = nullptr;
     int enc_variant = 0, dec_variant = 0;
+    uint32_t decode_wait_limit = 1u << 24;   // polls before a multi-workgroup decode gives up on a sibling workgroup (TSQA_ERR_STALL)
     char err[256] = {0};
     // optional timing (tsqa_profile_*): HIP event pairs on the launch stream, taken from a pool made when profiling is
     // switched on (nothing is created or destroyed between the events).  Kinds: 0 encode kernel, 1 decode kernel,

@@ -114,8 +114,8 @@ inline int launch_decode_kernels(tsqa_ctx* c, const uint8_t* container, const Fr
         if (int rc = c->reserve_duo(nblk)) return rc;
         if (hipMemsetAsync(c->duo_flags, 0, (size_t)nblk * DuoCfg::FLAG_STRIDE * sizeof(uint32_t), s) != hipSuccess) { c->set_error("hipMemsetAsync failed"); return TSQA_ERR_HIP; }
         const uint32_t groups = (nblk + 7u) / 8u;
-        if (three) hipLaunchKernelGGL(dec_duo_kernel<2>, dim3(24u * groups), dim3(SymCfg::T), lds_bytes, s, container, fr, nblk, out, status, c->duo_ring, c->duo_flags);
-        else hipLaunchKernelGGL(dec_duo_kernel<1>, dim3(16u * groups), dim3(SymCfg::T), lds_bytes, s, container, fr, nblk, out, status, c->duo_ring, c->duo_flags);
+        if (three) hipLaunchKernelGGL(dec_duo_kernel<2>, dim3(24u * groups), dim3(SymCfg::T), lds_bytes, s, container, fr, nblk, out, status, c->duo_ring, c->duo_flags, c->decode_wait_limit);
+        else hipLaunchKernelGGL(dec_duo_kernel<1>, dim3(16u * groups), dim3(SymCfg::T), lds_bytes, s, container, fr, nblk, out, status, c->duo_ring, c->duo_flags, c->decode_wait_limit);
         return 0;
     };
     const uint32_t cus = (uint32_t)c->n_cus;

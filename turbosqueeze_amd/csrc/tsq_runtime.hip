@@ -58,6 +58,8 @@ extern "C" int tsqa_create(int device, tsqa_ctx** out)
     if (!c) return TSQA_ERR_ARG;
     c->device = device;
     c->n_cus = prop.multiProcessorCount;
+    // (tests: the reference-named API makes its contexts itself; the wait limit of its multi-workgroup decodes comes from here)
+    if (const char* e = getenv("TSQ_AMD_DECODE_WAIT_LIMIT")) { const long v = atol(e); if (v > 0) c->decode_wait_limit = (uint32_t)v; }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return TSQA_ERR_HIP;
@@ -87,6 +89,7 @@ extern "C" void tsqa_destroy(tsqa_ctx* c)
 extern "C" const char* tsqa_last_error(const tsqa_ctx* c) { return c ? c->err : "null context"; }
 extern "C" int tsqa_device_id(const tsqa_ctx* c) { return c ? c->device : -1; }
 extern "C" void tsqa_set_kernel_variant(tsqa_ctx* c, int ev, int dv) { if (c) { c->enc_variant = ev; c->dec_variant = dv; } }
+extern "C" void tsqa_set_decode_wait_limit(tsqa_ctx* c, uint32_t polls) { if (c) c->decode_wait_limit = polls ? polls : 1u; }
 
 // Scratch in HBM, grown on demand and kept: slots (TSQ_OUTPUT_SZ per block, the reference's
 // per-block output buffer, tsq_context.cpp:89-143), per-block sizes, frame offsets, frame
@@ -382,6 +385,18 @@ extern "C" int tsqa_decompress_device(tsqa_ctx* c, const void* d_in, size_t n, v
     TSQ_HIP(c, hipMemcpyAsync(&sz, c->d_size, sizeof(sz), hipMemcpyDeviceToHost, s));
     TSQ_HIP(c, hipMemcpyAsync(&st, c->d_status, sizeof(st), hipMemcpyDeviceToHost, s));
     TSQ_HIP(c, hipStreamSynchronize(s));
+    if (st == kErrStall) {
+        // a workgroup of a several-workgroups-per-block decode did not get onto the GPU in time (other work held the CUs): the
+        // container is not at fault -- once more with one workgroup per block, which waits for nobody
+        const int keep = c->dec_variant;
+        c->dec_variant = 4;
+        rc = tsqa_decompress_device_async(c, d_in, n, nb, d_out, out_cap, c->d_size, c->d_status, s);
+        c->dec_variant = keep;
+        if (rc) return rc;
+        TSQ_HIP(c, hipMemcpyAsync(&sz, c->d_size, sizeof(sz), hipMemcpyDeviceToHost, s));
+        TSQ_HIP(c, hipMemcpyAsync(&st, c->d_status, sizeof(st), hipMemcpyDeviceToHost, s));
+        TSQ_HIP(c, hipStreamSynchronize(s));
+    }
     *out_size = (size_t)sz;
     return status_to_rc(c, st, "decompress");
 }
