@@ -80,9 +80,24 @@ struct StageCfgT {
     static constexpr uint32_t RING = 256;                          // symbol records between BUILDER and EMIT (four batches)
     static constexpr uint32_t LM = WINDOW ? TSQ_LM : TSQ_LM_LEAN, LF = WINDOW ? TSQ_LF : TSQ_LF_LEAN;
     static_assert((LM == 3u || LM == 4u) && LF >= 2u && LF < LM, "lags");
-    static constexpr uint32_t R = LM == 3u ? (WINDOW ? 10 : 8) : 10;   // tile records in flight (HASH runs at most R - LM tiles ahead of WALK)
-    static constexpr uint32_t OWN_MASK = (WINDOW || LM == 3u) ? 0x7FFFu : 0x3FFFu;   // owner image: hash folded to 15 bits (14 in the lean layout when it keeps ten records)
-    static constexpr uint32_t WIN = 71168;                        // input window ring: the last 64 KiB of input and what SCAN is ahead of MATCH (at most R tiles; a multiple of 64)
+#ifndef TSQ_X_R
+#define TSQ_X_R 11
+#endif
+    // tile records in flight (HASH runs at most R - LM tiles ahead of WALK).  Measured in the standard layout: 9 records 44.5 ms, 10 41.9,
+    // 11 41.1, 12 41.5, 13 41.1, 14 41.4 (the even counts, where the even and the odd tiles' wavefronts keep to their own slots, are the
+    // slower ones); the eleventh record has the room the input window's margin gave up.  The lean layout: 9, 10 or 11 make no difference.
+    static constexpr uint32_t R = LM == 3u ? (WINDOW ? 10 : 8) : (WINDOW ? TSQ_X_R : 10);
+#ifndef TSQ_X_OWNBITS
+#define TSQ_X_OWNBITS 15
+#endif
+    static constexpr uint32_t OWN_MASK = (WINDOW ? TSQ_X_OWNBITS == 15 : LM == 3u) ? 0x7FFFu : 0x3FFFu;   // owner image: hash folded to 15 bits (14 in the lean layout when it keeps ten records)
+    // input window ring: the last 64 KiB of input and what HASH may be ahead of MATCH and WALK: while they work on tile t, WALK has not
+    // finished it, so HASH is at tile t + R - LM at most -- 64 KiB + 7 tiles + a tile's own 64 bytes = 66 047; a multiple of 64
+#ifndef TSQ_X_WIN
+#define TSQ_X_WIN 66560
+#endif
+    static constexpr uint32_t WIN = TSQ_X_WIN;
+    static_assert(WIN % 64u == 0u && WIN > 65536u + (TSQ_X_R - 3u) * 64u + 63u, "window margin");
     static constexpr uint32_t W16 = 16;                           // word offset of the uint4-per-lane input words
     static constexpr uint32_t ARR = 16 + 256;                     // word offset of the per-lane words: four groups of four words per lane
     static constexpr uint32_t REC_WORDS = ARR + 16 * 64;
