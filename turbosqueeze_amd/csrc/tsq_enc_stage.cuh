@@ -1311,11 +1311,9 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
         if (kind == kEvEnd) break;
         const uint32_t ev_base = ea & ~63u;
         const uint32_t new_tile = ev_base != base ? 1u : 0u;
-        if (new_tile | (kind == kEvSeg ? 1u : 0u)) {
-            // ---- a new tile: what is pending goes to the builder, then the tile's record.  (A later segment of a tile that a query
-            //      opened reads the record again: WALK patches the hazard lanes it decides itself into the class words, and it has
-            //      done so for every lane of a segment before the segment's event.)
-            if (new_tile) { flush_pending(); qmask = 0; }
+        // the tile's record: its class words (a later segment of a tile that a query opened reads the record again: WALK patches the
+        // hazard lanes it decides itself into the class words, and it has done so for every lane of a segment before the segment's event)
+        auto open_tile = [&]() {
             base = ev_base;
             const uint32_t t = base >> 6;
             volatile lds_u32_t* arr = recs + (t % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::ARR + lane * 4u;
@@ -1329,8 +1327,8 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
             __hip_atomic_store(&ctl[kCtlAccounted], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             TSQ_DELAY(7);
             TSQ_CNT(15, 1);
-        }
-        if (kind == kEvSeg) {
+        };
+        auto account_segment = [&]() {
             // ---- the segment's effect on the symbol state, O(1) from its masks.  `dsym` symbols close (matches and
             //      the literal runs in front of them); the state afterwards hangs on the last match.
             const uint64_t V = (uint64_t)eb | ((uint64_t)ec << 32);
@@ -1360,7 +1358,21 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
                 origin = origin_n;
             }
             Vt |= V; Mt |= M;
-        } else {
+        };
+        // (the usual event -- a tile's one segment -- has a straight path of its own: a branch costs a wavefront 25 cycles)
+        if (__builtin_expect((kind == kEvSeg ? new_tile : 0u) != 0u, 1)) {
+            flush_pending(); qmask = 0;
+            open_tile();
+            account_segment();
+            continue;
+        }
+        if (new_tile | (kind == kEvSeg ? 1u : 0u)) {
+            // ---- a new tile: what is pending goes to the builder, then the tile's record
+            if (new_tile) { flush_pending(); qmask = 0; }
+            open_tile();
+        }
+        if (kind == kEvSeg) account_segment();
+        else {
             const uint32_t i = ea, cand = eb;
             uint32_t k = ec & 0xFFu;
             const uint32_t L = i - base;
