@@ -639,11 +639,8 @@ private:
                 // a sibling workgroup of a several-workgroups-per-block decode did not get onto the GPU in time: the batch is still on
                 // the device -- once more with one workgroup per block
                 hipStream_t s = l.dev->stream;
-                const int keep = l.dev->dec_variant;
-                l.dev->dec_variant = 4;
                 bool good = hipMemsetAsync(l.dev->d_status, 0, sizeof(int32_t), s) == hipSuccess;
-                good = good && l.dev->launch_decode(l.d_in, f.n_blocks, l.d_out, l.dev->d_status, s) == TSQA_OK;
-                l.dev->dec_variant = keep;
+                good = good && l.dev->launch_decode(l.d_in, f.n_blocks, l.d_out, l.dev->d_status, s, 4) == TSQA_OK;
                 good = good && hipMemcpyAsync(l.h_status, l.dev->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s) == hipSuccess;
                 good = good && hipStreamSynchronize(s) == hipSuccess;
                 mk.at("decompress: batch decoded again (stall)");
@@ -949,12 +946,8 @@ extern "C" void tsqDecode(uint8_t* inputBlock, uint8_t* outputBlock, uint32_t* o
     (void)hipMemcpyAsync(l.h_status, l.dev->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s);
     if (hipStreamSynchronize(s) != hipSuccess) return;
     if (*l.h_status == tsq::kErrStall) {          // (a sibling workgroup did not get onto the GPU in time: once more on one workgroup)
-        const int keep = l.dev->dec_variant;
-        l.dev->dec_variant = 4;
         (void)hipMemsetAsync(l.dev->d_status, 0, sizeof(int32_t), s);
-        const int rc = l.dev->launch_decode(l.d_in, 1, l.d_out, l.dev->d_status, s);
-        l.dev->dec_variant = keep;
-        if (rc != TSQA_OK) return;
+        if (l.dev->launch_decode(l.d_in, 1, l.d_out, l.dev->d_status, s, 4) != TSQA_OK) return;
         (void)hipMemcpyAsync(l.h_status, l.dev->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s);
         if (hipStreamSynchronize(s) != hipSuccess) return;
     }

@@ -55,7 +55,9 @@ struct tsqa_ctx {
     // general form: block b at d_in + b * stride, streams to slots_out[b * TSQ_OUTPUT_SZ], sizes to sizes_out[b]
     int launch_encode_to(const void* d_in, size_t n, size_t readable, size_t stride, uint32_t ext, uint8_t* slots_out,
                          uint32_t* sizes_out, int32_t* status, hipStream_t s);
-    int launch_decode_frames(const void* d_streams, const tsq::FrameInfo* d_frames, uint32_t n_blocks, void* d_out, int32_t* status, hipStream_t s);
+    // (variant < 0: the context's decode variant; the retry after TSQA_ERR_STALL passes 4 -- one workgroup per block -- without touching
+    //  the context's setting, which other threads of the scheduler read)
+    int launch_decode_frames(const void* d_streams, const tsq::FrameInfo* d_frames, uint32_t n_blocks, void* d_out, int32_t* status, hipStream_t s, int variant = -1);
     int launch_pack(size_t n, uint32_t ext, void* d_out, size_t out_cap, uint64_t* d_out_size, int32_t* status, hipStream_t s);
-    int launch_decode(const void* d_container, uint32_t n_blocks, void* d_out, int32_t* status, hipStream_t s);
+    int launch_decode(const void* d_container, uint32_t n_blocks, void* d_out, int32_t* status, hipStream_t s, int variant = -1);
 };

@@ -92,7 +92,7 @@ inline int launch_encode_kernels(tsqa_ctx* c, const uint8_t* in, size_t n, size_
 #undef TSQ_LAUNCH_ENC
 
 inline int launch_decode_kernels(tsqa_ctx* c, const uint8_t* container, const FrameInfo* frames, uint32_t n_blocks, uint8_t* out,
-                                 int32_t* status, hipStream_t s)
+                                 int32_t* status, hipStream_t s, int variant = -1)
 {
     static std::atomic<uint64_t> attr_devices{0};
     {
@@ -100,7 +100,7 @@ inline int launch_decode_kernels(tsqa_ctx* c, const uint8_t* container, const Fr
         const uint32_t bytes[1] = {SymLds::total};
         if (int rc = raise_lds_limit(c, attr_devices, fns, bytes)) return rc;
     }
-    const int v = c->dec_variant;
+    const int v = variant >= 0 ? variant : c->dec_variant;
     if (v == 1) { hipLaunchKernelGGL(dec_serial_kernel, dim3(n_blocks), dim3(64), 0, s, container, frames, out, status); return 0; }
     if (v == 8 || v == 9) { c->set_error("kernel variant %d is not built", v); return TSQA_ERR_ARG; }
     // Few blocks (every GPU of a multi-GPU job on enwik9): several workgroups per block on different CUs of one XCD -- the block's

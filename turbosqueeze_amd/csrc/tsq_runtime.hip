@@ -257,19 +257,19 @@ int tsqa_ctx::launch_pack(size_t n, uint32_t ext, void* d_out, size_t out_cap, u
     return TSQA_OK;
 }
 
-int tsqa_ctx::launch_decode_frames(const void* d_streams, const FrameInfo* d_frames, uint32_t n_blocks, void* d_out, int32_t* status, hipStream_t s)
+int tsqa_ctx::launch_decode_frames(const void* d_streams, const FrameInfo* d_frames, uint32_t n_blocks, void* d_out, int32_t* status, hipStream_t s, int variant)
 {
     const bool timed = prof_begin(1, s);
-    int rc = launch_decode_kernels(this, static_cast<const uint8_t*>(d_streams), d_frames, n_blocks, static_cast<uint8_t*>(d_out), status, s);
+    int rc = launch_decode_kernels(this, static_cast<const uint8_t*>(d_streams), d_frames, n_blocks, static_cast<uint8_t*>(d_out), status, s, variant);
     if (rc) { if (timed) prof_used[1]--; return rc; }
     if (timed) prof_end(1, s);
     TSQ_HIP(this, hipGetLastError());
     return TSQA_OK;
 }
 
-int tsqa_ctx::launch_decode(const void* d_container, uint32_t n_blocks, void* d_out, int32_t* status, hipStream_t s)
+int tsqa_ctx::launch_decode(const void* d_container, uint32_t n_blocks, void* d_out, int32_t* status, hipStream_t s, int variant)
 {
-    return launch_decode_frames(d_container, frames, n_blocks, d_out, status, s);
+    return launch_decode_frames(d_container, frames, n_blocks, d_out, status, s, variant);
 }
 
 // ---- public device-resident entry points ----
