@@ -37,10 +37,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def pmc_traffic(kernel_substr: str, fingerprint: str):
+def pmc_traffic(kernel_substr: str, blocks: int, fingerprint: str):
     """HBM-side bytes per launch of a kernel from the rocprofv3 PMC summary of this same command
     (tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes), corrected as
     MI355X_MICROARCH.md prescribes for gfx950: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
+    The summary is keyed by kernel AND launch shape ("<kernel>@<blocks>", tools/pmc_summary.py): the entry taken is the one of
+    the timed job's own grid size -- the profiled command also launches the codec kernels at 1 024 blocks (`throughput`).
     bench.py cannot read PMCs itself (rocprofv3 wraps the process): it takes the newest stored summary ONLY IF that summary was
     made from the kernel sources that are running now (same `kernel_fingerprint`); otherwise the field is null.
     Returns (bytes, source) or (None, reason)."""
@@ -52,9 +54,14 @@ def pmc_traffic(kernel_substr: str, fingerprint: str):
         d = json.load(open(files[-1]))
         if d.get("kernel_fingerprint") != fingerprint:
             return None, f"{os.path.relpath(files[-1], ROOT)} was made from other kernel sources ({d.get('kernel_fingerprint')} != {fingerprint})"
-        f = next(v["per_dispatch"] for k, v in d["fetch"].items() if kernel_substr in k)
-        w = next(v["per_dispatch"] for k, v in d["write"].items() if kernel_substr in k)
-        return int((2 * f + w) * 1024), os.path.relpath(files[-1], ROOT)
+        want = f"@{blocks}"
+
+        def pick(table):
+            shaped = [v["per_dispatch"] for k, v in table.items() if kernel_substr in k and k.endswith(want)]
+            if shaped:
+                return shaped[0]
+            raise KeyError(f"no entry for a '{kernel_substr}' kernel at {blocks} blocks")
+        return int((2 * pick(d["fetch"]) + pick(d["write"])) * 1024), os.path.relpath(files[-1], ROOT) + f" ({kernel_substr}*{want})"
     except Exception as e:
         return None, f"unreadable PMC summary: {e}"
 
@@ -118,7 +125,8 @@ def cpu_baseline(sample_bytes: int, ext: int, reps: int = 5):
     eff = lambda k: round(ideal[k] / (one[k] * ideal["threads"]), 4) if one[k] > 0 else None
     strip = lambda r: {k: v for k, v in r.items() if k not in ("rt_median_s",)}
     return {
-        "value": ideal["roundtrip_GBps"], "unit": "GB/s", "cores": ideal["threads"], "kind": kind,
+        # `cores` = the CPUs this process may use (affinity mask and cgroup quota); `threads` = the pthreads of the best run
+        "value": ideal["roundtrip_GBps"], "unit": "GB/s", "cores": cores, "threads": ideal["threads"], "kind": kind,
         "sample": f"{sample_bytes} B of the same enwik9-shaped text; idealised block-parallel pthreads (block i -> thread i % T), "
                   f"threads pinned, pages first-touched by their owner, 1 warm + {reps} timed passes, value = median round trip; "
                   f"host shows {hw} hardware threads, {quota_note}; roundtrip_ok={ideal['ok'] and shaped['ok'] and one['ok']} ratio={ideal['ratio']:.4f}",
@@ -197,6 +205,52 @@ def roofline_entries(n, comp_bytes, enc_ms, enc_n, dec_ms, dec_n, peak_measured)
     return alg, enc, dec, dom, enc_avg, dec_avg
 
 
+def host_gather_step(tsq, sharding, codec, dev, n, ext, steps, check_oracle):
+    """The sharded step of bench.py --gpus N with a world of ONE rank and no process group: encode the owned blocks -> every frame by
+    DMA to its place in ONE container in host memory (/dev/shm, hipHostRegister'ed) -> walk the frames, bring them back, decode."""
+    import torch
+    lay = sharding.ShardLayout(n, 0, 1)
+    host = tsq.synth.text(n, seed=1)
+    d_shard = torch.from_numpy(lay.pack_input(host)).to(dev)
+    expect = torch.from_numpy(lay.expected_output(host)).to(dev)
+    hc = sharding.HostContainer("tsq_bench_gather_%d" % os.getpid(), tsq.container_bound(n), create=True)
+    hc.register()
+    try:
+        sc = sharding.ShardedCodec(lay, sharding.DeviceBlocks(codec), hc, ext)
+        d_back = torch.empty(max(lay.shard_bytes, 1), dtype=torch.uint8, device=dev)
+        size = [0]
+
+        def step():
+            size[0] = sc.compress(d_shard)
+            sc.decompress(size[0], d_back)
+        step()
+        for k in sc.seconds:
+            sc.seconds[k] = 0.0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert torch.equal(d_back[:lay.shard_bytes], expect), "host-gather round trip mismatch"
+        equal = None
+        if check_oracle:
+            from oracle import pyoracle
+            want = pyoracle.Oracle().compress(host, ext, threads=min(32, os.cpu_count() or 1))
+            equal = bool(len(want) == size[0] and bytes(hc.array[:size[0]]) == want)
+            assert equal, "the host-gathered container differs from the oracle's"
+        out = {"what": "the N > 1 step at a world of one rank: encode -> frames DMA'd to one container in host memory -> frame walk, frames back, decode "
+                       "(both PCIe legs inside the step; no process group, so no all-gather and no barriers)",
+               "value": round(aggregate_value(n, dt, steps), 4), "unit": "GB/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
+               "step_breakdown_ms": {k: round(v / steps * 1e3, 3) for k, v in sc.seconds.items()},
+               "container_bytes": size[0], "container_equals_oracle": equal}
+    finally:
+        hc.close()
+    del d_shard, expect
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,6 +264,8 @@ def main():
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the extra weak-scaling measurement")
     ap.add_argument("--no-throughput", action="store_true", help="N = 1: skip the extra chip-filling measurement (4 GiB of the same text = 1 024 blocks)")
     ap.add_argument("--throughput-size", type=int, default=4 << 30)
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the extra sections (the other level, config 5's inputs, the host-gather step)")
+    ap.add_argument("--config5-size", type=int, default=1 << 30)
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = production, 1 = serial baselines, 5 = round 2's encoder from the A/B library)")
     args = ap.parse_args()
 
@@ -237,15 +293,16 @@ def main():
     codec = tsq.DeviceCodec(local_rank, ab=args.variant == 5)
     codec.set_variant(args.variant, args.variant if args.variant in (0, 1) else 0)
 
-    def single_gpu_job(seed, steps, warmup, check_oracle=False, n=n, nb=nb):
+    def single_gpu_job(seed, steps, warmup, check_oracle=False, n=n, nb=nb, ext=None, make=None):
         """The N=1 step on this rank's own job.  -> (dt, comp_bytes, enc/dec kernel ms+launches, call ms, container == oracle's)"""
-        host = tsq.synth.text(n, seed=seed)
+        ext = args.ext if ext is None else ext
+        host = make(n, seed) if make else tsq.synth.text(n, seed=seed)
         src = torch.from_numpy(host).to(dev)
         container = torch.empty(tsq.container_bound(n), dtype=torch.uint8, device=dev)
         back = torch.empty(n, dtype=torch.uint8, device=dev)
 
         def step():
-            codec.compress_async(src, args.ext, container)
+            codec.compress_async(src, ext, container)
             codec.decompress_async(container, nb, back)
 
         for _ in range(warmup):                           # W untimed, unprofiled steps
@@ -263,7 +320,7 @@ def main():
         total_out, status = codec.last_size_status()
         assert status == 0 and total_out == n, (status, total_out)
         assert torch.equal(back, src), "round trip mismatch"
-        codec.compress_async(src, args.ext, container)
+        codec.compress_async(src, ext, container)
         torch.cuda.synchronize()
         comp_bytes, status = codec.last_size_status()
         assert status == 0
@@ -271,7 +328,7 @@ def main():
         if check_oracle:
             # ... and, outside the timed region, the timed job's container byte for byte against the CPU oracle (the checker)
             from oracle import pyoracle
-            want = pyoracle.Oracle().compress(host, args.ext, threads=min(32, os.cpu_count() or 1))
+            want = pyoracle.Oracle().compress(host, ext, threads=min(32, os.cpu_count() or 1))
             got = container[:comp_bytes].cpu().numpy()
             oracle_equal = bool(len(want) == comp_bytes and got.tobytes() == want)
             assert oracle_equal, "the timed job's container differs from the oracle's"
@@ -288,7 +345,7 @@ def main():
         traffic, traffic_src = (None, "PMC summaries are collected for the default job only")
         fingerprint = tsq.source_fingerprint()
         if args.variant == 0 and args.ext == 0 and n == 1_000_000_000:
-            traffic, traffic_src = pmc_traffic("enc_" if dom[0] == "encode" else "dec_", fingerprint)
+            traffic, traffic_src = pmc_traffic("enc_" if dom[0] == "encode" else "dec_", nb, fingerprint)
         cmp_avg = cmp_ms / max(cmp_n, 1) * 1e-3
         dcm_avg = dcm_ms / max(dcm_n, 1) * 1e-3
         line = {
@@ -336,9 +393,58 @@ def main():
                 "algorithmic_bytes_per_launch": t_alg,
                 "roofline_encode": te_e, "roofline_decode": td_e,     # (N + C) / t against 8 TB/s and against the measured copy
             }
+        if not args.no_extras:
+            # ---- what a user of the reference sees beyond the published --no-ext row, same HIP events, every
+            #      timed container compared with the oracle's outside the timed region.  Short runs (1 warm + 2 timed steps).
+            def kernel_line(job_n, dtj, comp, kern, equal, steps_):
+                e_ms, e_n, d_ms, d_n = kern
+                e_avg, d_avg = e_ms / max(e_n, 1) * 1e-3, d_ms / max(d_n, 1) * 1e-3
+                return {"job_bytes": job_n, "blocks": (job_n + tsq.BLOCK_SZ - 1) // tsq.BLOCK_SZ, "ratio": round(comp / job_n, 5),
+                        "value": round(aggregate_value(job_n, dtj, steps_), 4), "unit": "GB/s",
+                        "encode_kernel_ms": round(e_avg * 1e3, 3), "decode_kernel_ms": round(d_avg * 1e3, 3),
+                        "encode_kernel_GBps": round(job_n / e_avg / 1e9, 3) if e_avg > 0 else 0.0,
+                        "decode_kernel_GBps": round(job_n / d_avg / 1e9, 3) if d_avg > 0 else 0.0,
+                        "roofline_frac_encode": round((job_n + comp) / e_avg / 1e9 / HBM_PEAK_GBS, 6) if e_avg > 0 else 0.0,
+                        "roofline_frac_decode": round((job_n + comp) / d_avg / 1e9 / HBM_PEAK_GBS, 6) if d_avg > 0 else 0.0,
+                        "container_equals_oracle": equal}
+            xsteps = 2
+            # (a) the reference CLI's default level: extensions ON (sample/main.cpp:130,144), the same 10^9 B of text
+            xdt, xcomp, xkern, _, xeq = single_gpu_job(1, xsteps, 1, check_oracle=not args.no_oracle_check, ext=1 - args.ext)
+            key = "ext1" if args.ext == 0 else "ext0"
+            line[key] = dict(kernel_line(n, xdt, xcomp, xkern, xeq, xsteps),
+                             workload=f"the same {n} B of enwik9-shaped text, {'with-extensions' if args.ext == 0 else '--no-ext'} level "
+                                      f"({'the reference CLI default, sample/main.cpp:130' if args.ext == 0 else 'the published row'})")
+            # (b) BASELINE config 5's inputs at one GPU's scale, with extensions: zeros / random / 50 % mix
+            c5n = args.config5_size
+            makers = {"zeros": lambda m, sd: np.zeros(m, dtype=np.uint8), "random": lambda m, sd: tsq.synth.random_bytes(m, 3),
+                      "mix": lambda m, sd: tsq.synth.mix(m, 3)}
+            c5 = {"workload": f"{c5n} B per input ({(c5n + tsq.BLOCK_SZ - 1) // tsq.BLOCK_SZ} blocks), with-extensions level, device-resident, bit-exact round trip"}
+            for kind, mk in makers.items():
+                kdt, kcomp, kkern, _, keq = single_gpu_job(3, xsteps, 1, check_oracle=not args.no_oracle_check, n=c5n,
+                                                           nb=(c5n + tsq.BLOCK_SZ - 1) // tsq.BLOCK_SZ, ext=1, make=mk)
+                c5[kind] = kernel_line(c5n, kdt, kcomp, kkern, keq, xsteps)
+            line["config5"] = c5
+            # (c) the N > 1 step's shape at a world of one rank: frames placed in ONE container in host memory, barrier, owned frames
+            #     back and decoded -- both PCIe legs and the host gather inside the step, so that the first point of the 1 -> 8 curve
+            #     can be read against points that carry them (bench.py --gpus N runs exactly this per rank)
+            line["host_gather"] = host_gather_step(tsq, sharding, codec, dev, n, args.ext, args.steps, not args.no_oracle_check)
         if not args.no_cpu_baseline:
             # bounded sample, but never fewer blocks than 2 per host thread (block-parallel CPU code)
-            line["cpu_baseline"] = cpu_baseline(min(n, args.cpu_sample), args.ext)
+            line["cpu_baseline"] = cb = cpu_baseline(min(n, args.cpu_sample), args.ext)
+            # the north star's criterion as a number: GPU decode over the reference's multithreaded CPU decode on this box's host cores
+            dk = line["decode_kernel_GBps"]
+            tk = line.get("throughput", {}).get("decode_kernel_GBps")
+            shaped_d, ideal_d = cb["reference_shaped"]["decode_GBps"], cb["decode_GBps"]
+            line["decode_vs_cpu_mt"] = {
+                "what": "device-resident decode GB/s of ONE MI355X over the CPU decode GB/s on this box's host cores (reference-shaped pipeline: "
+                        "tsq_threads.cpp's reader / workers / ordered writer; idealised: block-parallel threads, no writer); the north star asks >= 10x at 8 GPUs",
+                "gpu_decode_call_GBps": line["decode_GBps"], "gpu_decode_kernel_GBps": dk, "gpu_decode_kernel_GBps_1024_blocks": tk,
+                "cpu_reference_shaped_GBps": shaped_d, "cpu_idealised_GBps": ideal_d, "cpu_cores": cb["cores"], "cpu_threads": cb["threads"],
+                "x_reference_shaped": round(line["decode_GBps"] / shaped_d, 2) if shaped_d else None,
+                "x_idealised": round(line["decode_GBps"] / ideal_d, 2) if ideal_d else None,
+                "x_reference_shaped_kernel_1024_blocks": round(tk / shaped_d, 2) if tk and shaped_d else None,
+                "x_idealised_kernel_1024_blocks": round(tk / ideal_d, 2) if tk and ideal_d else None,
+            }
     else:
         # ---- one job, blocks dealt round-robin over the ranks, container gathered in host memory
         lay = sharding.ShardLayout(n, rank, world)

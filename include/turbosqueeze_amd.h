@@ -194,6 +194,9 @@ int tsqa_sharded_place_async(tsqa_ctx *ctx, const void *d_slots, const uint32_t 
 int tsqa_sharded_fetch_decode_async(tsqa_ctx *ctx, const void *host_container, size_t container_size, uint32_t rank, uint32_t world,
                                     void *d_streams, size_t streams_cap, void *d_out, size_t out_cap, int32_t *d_status, uint64_t *total,
                                     void *hip_stream);
+/* When *d_status of tsqa_sharded_fetch_decode_async reads TSQA_ERR_STALL: the owned frames and their descriptors are still on the
+ * device; this decodes them again with one workgroup per block (which waits for nobody) and reports in *d_status again. */
+int tsqa_sharded_decode_again_async(tsqa_ctx *ctx, const void *d_streams, void *d_out, int32_t *d_status, void *hip_stream);
 
 /* The measured copy bandwidth of this GPU (bytes read + bytes written per second, GB/s = 1e9 B/s) by a plain
  * grid-stride 16-byte copy kernel over `bytes` of HBM: the second denominator beside the 8 TB/s specification when a
@@ -272,6 +275,14 @@ uint32_t tsqa_compress_async_cb(struct TSQCompressionContext_MT *ctx, uint8_t *i
 uint32_t tsqa_decompress_async_cb(struct TSQDecompressionContext_MT *ctx, uint8_t *in, size_t szin, bool infile,
                                   uint8_t **out, size_t *szout, bool outfile,
                                   tsqa_done_fn done, tsqa_progress_fn progress, void *user);
+
+/* tsqEncode takes the reference encoder's look-ahead (the ~67 bytes it reads behind inputBlock[inputSize-1],
+ * tsq_encode.cpp:74,108,126,162) with process_vm_readv, which stops at an unmapped page instead of faulting.  Where a seccomp
+ * profile or sandbox refuses that call the look-ahead is seen as zeros and a loop over the blocks of ONE buffer no longer gives the
+ * container's streams at block edges (every stream stays valid).  One line on stderr says so the first time; this call lets a
+ * caller detect it: 0 = not yet known (no tsqEncode call so far), 1 = look-ahead read from the caller's memory,
+ * 2 = refused by the system (zeros), 3 = switched off with TSQ_AMD_ENCODE_NO_LOOKAHEAD. */
+int tsqa_encode_lookahead_state(void);
 
 #ifdef __cplusplus
 }

@@ -170,11 +170,18 @@ def test_bad_arguments(tsq):                              # tsq_threads.cpp:415-
     assert tsq.tsq_decompress_mt(b"TSQ1" + bytes(12) + bytes(40)) is None   # n_blocks == 0
 
 
-@pytest.mark.parametrize("inmem_max", ["", "1"])           # whole file in memory / streamed through pinned staging
-def test_file_modes(tsq, oracle, tmp_path, inmem_max, monkeypatch):   # sample/main.cpp:144,160 use file mode
+# whole file in memory / streamed through pinned staging; the output side: collected in memory (small file), the MAPPED file whose
+# pages fallocate provides ahead of the batches (TSQ_AMD_FILE_MAP_MIN=1 makes a 12 MB file "large"), positional writes
+# (TSQ_AMD_FILE_NO_MMAP)
+@pytest.mark.parametrize("inmem_max,sink", [("", ""), ("1", ""), ("", "map"), ("1", "map"), ("", "pwrite"), ("1", "pwrite")])
+def test_file_modes(tsq, oracle, tmp_path, inmem_max, sink, monkeypatch):   # sample/main.cpp:144,160 use file mode
     if inmem_max:
         monkeypatch.setenv("TSQ_AMD_FILE_INMEM_MAX", inmem_max)
         monkeypatch.setenv("TSQ_AMD_FILE_BATCH_BLOCKS", "1")
+    if sink:
+        monkeypatch.setenv("TSQ_AMD_FILE_MAP_MIN", "1")
+    if sink == "pwrite":
+        monkeypatch.setenv("TSQ_AMD_FILE_NO_MMAP", "1")
     L = tsq.lib()
     host = tsq.synth.text(3 * (1 << 22) + 99999, seed=41)
     src = tmp_path / "in.bin"; mid = tmp_path / "out.tsq"; dst = tmp_path / "back.bin"
@@ -189,6 +196,33 @@ def test_file_modes(tsq, oracle, tmp_path, inmem_max, monkeypatch):   # sample/m
     assert L.tsqDecompress_MT(d, C.c_char_p(str(mid).encode()), 0, True, outpp2, None, True)
     L.tsqDeallocateContextDecompression_MT(d)
     assert dst.read_bytes() == host.tobytes()
+
+
+def test_mapped_output_larger_than_one_allocation_step(tsq, oracle, tmp_path):
+    """A file output above 64 MiB (the default TSQ_AMD_FILE_MAP_MIN) is written through the mapping of a file whose pages are
+    allocated by fallocate in 64 MiB steps, a bounded distance ahead of the batches (tsq_compat.hip: Sink::ensure_allocated): the
+    decompressed file of a 40-block container crosses two steps; nothing may be copied into a range that was not allocated, and
+    the file ends at its exact length."""
+    L = tsq.lib()
+    host = tsq.synth.text(40 * (1 << 22) + 4321, seed=47)
+    blob = oracle.compress(host, 0, threads=4)
+    mid = tmp_path / "big.tsq"; dst = tmp_path / "big.bin"
+    mid.write_bytes(blob)
+    d = L.tsqAllocateContextDecompression_MT(False)
+    outp = C.c_char_p(str(dst).encode()); outpp = C.cast(C.pointer(outp), C.POINTER(C.c_void_p))
+    assert L.tsqDecompress_MT(d, C.c_char_p(str(mid).encode()), 0, True, outpp, None, True)
+    L.tsqDeallocateContextDecompression_MT(d)
+    assert os.path.getsize(dst) == host.size
+    assert dst.read_bytes() == host.tobytes()
+
+
+def test_encode_lookahead_state_is_reported(tsq, oracle):
+    """tsqEncode takes the reference's look-ahead behind a block with process_vm_readv; a caller can ask whether that worked
+    (include/turbosqueeze_amd.h: tsqa_encode_lookahead_state): 1 = read, 2 = refused by the system (zeros seen)."""
+    L = tsq.lib()
+    data = tsq.synth.text(70000, seed=48).tobytes()
+    assert tsq.tsq_encode(data[:50000], 0) is not None
+    assert L.tsqa_encode_lookahead_state() in (1, 2)
 
 
 def test_async_chain_ordering(tsq, oracle):               # test/test.cpp:202-331

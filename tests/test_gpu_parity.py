@@ -479,6 +479,42 @@ def test_sharded_fetch_decode_refuses_a_container_of_another_job(tsq, oracle):
         hc.close()
 
 
+def test_sharded_decode_stall_is_retried(tsq, oracle):
+    """A GPU of a sharded job holds few blocks, so its decode always takes the several-workgroups-per-block kernels; with the wait
+    limit at one poll they give up at once (TSQA_ERR_STALL).  ShardedCodec.decompress must then decode the frames, still on the
+    device, again on one workgroup per block (tsqa_sharded_decode_again_async) instead of failing a good container."""
+    import torch
+    from turbosqueeze_amd import sharding
+    B = 1 << 22
+    n = 11 * B + 4567
+    host = tsq.synth.text(n, seed=58)
+    lay = sharding.ShardLayout(n, 0, 1)
+    hc = sharding.HostContainer("tsq_test_stall_%d" % os.getpid(), tsq.container_bound(n), create=True)
+    hc.register()
+    c = tsq.DeviceCodec(0)
+    try:
+        blocks = sharding.DeviceBlocks(c)
+        sc = sharding.ShardedCodec(lay, blocks, hc, 0)
+        d_shard = torch.from_numpy(lay.pack_input(host)).cuda()
+        size = sc.compress(d_shard)
+        assert bytes(hc.array[:size]) == oracle.compress(host, 0, threads=4)
+        d_back = torch.zeros(lay.shard_bytes, dtype=torch.uint8, device="cuda")
+        c.set_decode_wait_limit(1)
+        assert sc.decompress(size, d_back) == n
+        assert getattr(blocks, "stall_retries", 0) == 1                      # the first attempt did give up, the second one decoded
+        assert torch.equal(d_back, torch.from_numpy(lay.expected_output(host)).cuda())
+        # the stream-ordered C call alone reports the code
+        c.sharded_fetch_decode_async(hc.ptr, size, 0, 1, blocks.slots, d_back)
+        torch.cuda.synchronize()
+        assert c.status() == 7
+        c.sharded_decode_again_async(blocks.slots, d_back)
+        torch.cuda.synchronize()
+        assert c.status() == 0
+    finally:
+        c.close()
+        hc.close()
+
+
 def test_multi_workgroup_decode_beside_a_long_encode(tsq, oracle):
     """The multi-workgroup decoders hand chunk records from a block's PARSE workgroup(s) to its COPY workgroup and so need them
     resident together (tsq_dec_duo.cuh).  Here a 30-block container is decoded on one context while a 2 GiB encode (512 blocks:

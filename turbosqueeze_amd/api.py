@@ -17,7 +17,8 @@ BLOCK_SZ = 1 << 22
 OUTPUT_SZ = BLOCK_SZ + (BLOCK_SZ >> 2)
 
 ERRORS = {1: "no usable gfx950 device", 2: "HIP runtime error", 3: "bad argument", 4: "malformed container",
-          5: "malformed block stream", 6: "block expanded beyond TSQ_OUTPUT_SZ"}
+          5: "malformed block stream", 6: "block expanded beyond TSQ_OUTPUT_SZ",
+          7: "multi-workgroup decode stalled waiting for a sibling workgroup (the container may be fine: decode again with variant 4)"}
 
 
 class TsqError(RuntimeError):
@@ -139,6 +140,10 @@ def lib(ab=False) -> C.CDLL:
     L.tsqa_sharded_place_async.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, u64p, vp]
     L.tsqa_sharded_fetch_decode_async.restype = C.c_int
     L.tsqa_sharded_fetch_decode_async.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp, C.c_size_t, vp, u64p, vp]
+    L.tsqa_sharded_decode_again_async.restype = C.c_int
+    L.tsqa_sharded_decode_again_async.argtypes = [vp, vp, vp, vp, vp]
+    L.tsqa_encode_lookahead_state.restype = C.c_int
+    L.tsqa_encode_lookahead_state.argtypes = []
     L.tsqa_copy_probe_shape.restype = C.c_char_p
     L.tsqa_copy_probe_shape.argtypes = [vp]
     L.tsqa_measure_copy.restype = C.c_int
@@ -277,6 +282,13 @@ class DeviceCodec:
         if rc:
             raise self._err(rc)
         return int(total.value)
+
+    def sharded_decode_again_async(self, d_streams, d_out) -> None:
+        """After status() == 7 (TSQA_ERR_STALL) behind sharded_fetch_decode_async: the owned frames, still on the device, once
+        more on one workgroup per block."""
+        rc = self.L.tsqa_sharded_decode_again_async(self.h, d_streams.data_ptr(), d_out.data_ptr(), self._status.data_ptr(), self._stream())
+        if rc:
+            raise self._err(rc)
 
     def status(self) -> int:
         return int(self._status.item())

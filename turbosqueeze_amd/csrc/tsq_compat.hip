@@ -131,23 +131,26 @@ void complain_once(const char* what)
 // in one by one costs more than the copy.  A few threads touch them while the kernels run.
 struct Prefault {
     std::vector<std::thread> th;
-    // A mapped file (fd >= 0): its pages are allocated by fallocate, 64 MiB at a time from the start (one call allocates at several
-    // times the rate page faults or write() do on one file: tools/streamed_files.sh), ahead of the batches that land in it.
-    std::atomic<size_t> allocated{0};
-    void start(uint8_t* p, size_t n, int fd = -1) {
+    std::atomic<bool> stop{false};
+    // A mapped output file: its pages are provided by fallocate AHEAD of the batches that land in it (one call allocates at several
+    // times the rate page faults or write() do on one file: tools/streamed_files.sh).  The sink owns the allocation (Sink::ensure_allocated:
+    // Linux fallocate, never glibc's read-modify-write emulation, and nothing is ever copied into a range that was not allocated);
+    // this thread only keeps it a bounded distance in front of the write cursor, so that a lying container header cannot make it
+    // allocate more than the job ever writes.
+    void start_mapped(std::function<bool(size_t)> ensure, std::function<size_t()> cursor, size_t n) {
+        if (n < (size_t(64) << 20)) return;
+        th.emplace_back([this, ensure, cursor, n] {
+            const size_t ahead = size_t(1) << 30;
+            size_t done = 0;
+            while (!stop && done < n) {
+                const size_t want = cursor() + ahead < n ? cursor() + ahead : n;
+                if (want > done) { if (!ensure(want)) return; done = want; }
+                else std::this_thread::sleep_for(std::chrono::microseconds(500));
+            }
+        });
+    }
+    void start(uint8_t* p, size_t n) {
         if (!p || n < (size_t(64) << 20)) return;
-        if (fd >= 0) {
-            allocated = 0;
-            th.emplace_back([this, fd, n] {
-                const size_t step = size_t(64) << 20;
-                for (size_t a = 0; a < n; a += step) {
-                    const size_t len = n - a < step ? n - a : step;
-                    (void)posix_fallocate(fd, (off_t)a, (off_t)len);       // (on failure the pages simply come from the faults below)
-                    allocated = a + len;
-                }
-            });
-            return;
-        }
         {   // transparent huge pages where the system allows them on request: 2 MiB per fault instead of 4 KiB
             uintptr_t a0 = (reinterpret_cast<uintptr_t>(p) + 4095) & ~uintptr_t(4095);
             (void)madvise(reinterpret_cast<void*>(a0), (n - 4096) & ~size_t(4095), MADV_HUGEPAGE);
@@ -162,8 +165,10 @@ struct Prefault {
             th.emplace_back([p, a, len] { for (size_t o = 0; o < len; o += 4096) { volatile uint8_t* q = p + a + o; *q = *q; } });   // (keeps what is already there: the header)
         }
     }
+    // (the touching threads of a malloc'ed buffer run to completion; the allocator of a mapped file is told to stop)
     void join() { for (auto& t : th) t.join(); th.clear(); }
-    ~Prefault() { join(); }
+    void cancel() { stop = true; join(); }
+    ~Prefault() { cancel(); }
 };
 
 // ---- sequential byte source / sink over memory or FILE* ----
@@ -201,7 +206,36 @@ struct Source {
 
 struct Sink {
     uint8_t* mem = nullptr; size_t cap = 0, at = 0; FILE* f = nullptr; bool own = false; bool failed = false;
+    std::atomic<size_t> cursor{0};                        // `at` as the allocator thread of a mapped file may read it
     bool open_file(const char* path) { f = fopen(path, "wb"); own = true; return f != nullptr; }
+    // Mapped output files.  The file is ftruncate'd to its bound (sparse) and its pages are provided by fallocate(2), 64 MiB at a
+    // time from the start, before anything is copied into them: a memcpy into a page the file system cannot back (disk or quota
+    // full) would raise SIGBUS and kill the caller's process, where the positional-write path reports a failed job.  Linux fallocate
+    // is called directly: on a file system without it (NFS before 4.2, FUSE, vfat) glibc's posix_fallocate falls back to a
+    // read-one-byte-write-it-back emulation that races with the writers of the same range.  EOPNOTSUPP turns the sink into a
+    // positional writer (pwrite through the same descriptor); any other failure (ENOSPC, EDQUOT, EFBIG) fails the job.
+    std::mutex alloc_m;
+    size_t alloc_upto = 0;
+    bool no_falloc = false;
+    bool ensure_allocated(size_t upto) {
+        if (!mapped) return true;
+        std::lock_guard<std::mutex> g(alloc_m);
+        if (no_falloc || alloc_failed) return false;
+        if (upto > cap) upto = cap;
+        const size_t step = size_t(64) << 20;
+        while (alloc_upto < upto) {
+            const size_t len = cap - alloc_upto < step ? cap - alloc_upto : step;
+            int r;
+            do r = fallocate(map_fd, 0, (off_t)alloc_upto, (off_t)len); while (r != 0 && errno == EINTR);
+            if (r != 0) {
+                if (errno == EOPNOTSUPP || errno == ENOSYS) no_falloc = true; else alloc_failed = true;
+                return false;
+            }
+            alloc_upto += len;
+        }
+        return true;
+    }
+    std::atomic<bool> alloc_failed{false};
     // small file outputs: collected like a memory sink, written once at the end.  Larger ones are MAPPED at their bound and
     // filled like memory too (pinned staging + a CPU copy into the page cache, whose pages a background fallocate provides ahead of
     // the batches; the file is cut to its length at the end): write() calls on one file take the inode lock one after the other and
@@ -248,6 +282,12 @@ struct Sink {
             if (at == 0) (void)fflush(f);
             if (!io_par([](int fd, uint8_t* q, size_t len, off_t off) { return pwrite(fd, q, len, off); }, fileno(f), const_cast<uint8_t*>(p), n, at)) failed = true;
         }
+        else if (mapped && at + n <= cap && !ensure_allocated(at + n)) {
+            // no pages behind this range: the file system has no fallocate -> positional writes through the descriptor (a full disk is
+            // then an error return, not a signal); it has, and refused -> the job fails
+            if (alloc_failed) failed = true;
+            else if (!io_par([](int fd, uint8_t* q, size_t len, off_t off) { return pwrite(fd, q, len, off); }, map_fd, const_cast<uint8_t*>(p), n, at)) failed = true;
+        }
         else if (at + n <= cap) {
             const size_t k = mapped ? io_threads_for(n) : 1;      // (a mapped file: the copy takes the pages' minor faults, in a few threads)
             if (k <= 1) memcpy(mem + at, p, n);
@@ -261,6 +301,7 @@ struct Sink {
         }
         else failed = true;
         at += n;
+        cursor = at;
     }
     ~Sink() {
         if (mapped) { (void)munmap(mem, cap); ::close(map_fd); }
@@ -468,8 +509,16 @@ private:
                 j = std::move(q_.front());
                 q_.pop_front();
             }
+            if (verbose_) {
+                // tsq_threads.cpp:385-391,832-838: a verbose context prints every block's progress in front of the caller's callback
+                std::function<void(uint32_t, double)> user = std::move(j.progress);
+                j.progress = [user](uint32_t id, double p) { printf("Job %u progress: %.2f%%\r", id, p * 100.0); if (user) user(id, p); };
+            }
             bool ok = compress_ ? run_compress(j) : run_decompress(j);
-            if (verbose_) printf("turbosqueeze_amd: job %u %s\n", j.id, ok ? "completed" : "FAILED");
+            if (verbose_) {                                     // tsq_threads.cpp:367-373,814-821
+                if (ok) printf("Job %u completed successfully.\n", j.id);
+                else printf("Job %u failed.                \n", j.id);
+            }
             if (j.done) j.done(j.id, ok);                       // tsq_threads.cpp:256-262,657-663
             {
                 std::lock_guard<std::mutex> g(m_);
@@ -482,12 +531,22 @@ private:
     // ------------------------------------------------------------------ compression
     bool run_compress(Job& j) {
         Source src;
-        if (!src.open(j.in, j.szin, j.infile) || src.size == 0) return false;
+        if (!src.open(j.in, j.szin, j.infile) || src.size == 0) {
+            if (verbose_ && j.infile) printf("Error: could not open input file.\n");          // tsq_threads.cpp:298-301
+            return false;
+        }
         const size_t total = src.size;
         const uint32_t nb = (uint32_t)tsqa_block_count(total);       // tsq_threads.cpp:313
         Sink sink;
-        if (j.outfile) { if (!sink.open_file_buffered(j.out_path.c_str(), tsqa_container_bound(total))) return false; }
-        else if (!sink.open_mem(tsqa_container_bound(total))) return false;   // tsq_threads.cpp:339
+        if (j.outfile) {
+            if (!sink.open_file_buffered(j.out_path.c_str(), tsqa_container_bound(total))) {
+                if (verbose_) printf("Error: could not open output file.\n");                   // tsq_threads.cpp:323-326
+                return false;
+            }
+        } else if (!sink.open_mem(tsqa_container_bound(total))) {                               // tsq_threads.cpp:339
+            if (verbose_) printf("Error: could not allocate output buffer.\n");                 // tsq_threads.cpp:343-346
+            return false;
+        }
 
         uint8_t header[16];                                          // tsq_threads.cpp:333-335,355-359
         memcpy(header, "TSQ1", 4); memcpy(header + 4, &nb, 4);
@@ -503,7 +562,7 @@ private:
         const uint32_t batch = job_batch(nb, stage_in || stage_out);
         Marks mk; mk.at("compress: buffers opened");
         Prefault touch;
-        if (sink.mapped) touch.start(sink.mem, total - total / 4, sink.map_fd);       // (the bound is 1.25x; text lands at 0.6x)
+        if (sink.mapped) touch.start_mapped([&sink](size_t upto) { return sink.ensure_allocated(upto); }, [&sink] { return sink.cursor.load(); }, sink.cap);
         else if (!stage_out) touch.start(sink.mem, sink.cap < total ? sink.cap : total);
         auto drain_one = [&]() {
             InFlight f = fly.front(); fly.pop_front();
@@ -593,7 +652,7 @@ private:
         while (ok && !fly.empty()) drain_one();
         for (const InFlight& f : fly) (void)issued_[f.lane]->wait();    // (after a failure: no feeder may still be working on this job's buffers)
         for (auto& l : lanes_) { (void)hipSetDevice(l.dev->device); (void)hipStreamSynchronize(l.dev->stream); }
-        touch.join();                                                 // nobody may still be touching the buffer when it is freed
+        touch.cancel();                                               // nobody may still be touching (or allocating behind) the buffer when it is freed
         if (!sink.finish()) ok = false;
         if (!j.outfile) {
             if (ok) { *j.out = sink.mem; *j.szout = sink.at; }       // tsq_threads.cpp:375-379; caller free()s
@@ -605,12 +664,21 @@ private:
     // ------------------------------------------------------------------ decompression
     bool run_decompress(Job& j) {
         Source src;
-        if (!src.open(j.in, j.szin, j.infile)) return false;
+        if (!src.open(j.in, j.szin, j.infile)) {
+            if (verbose_ && j.infile) printf("Error opening input file: %s\n", reinterpret_cast<const char*>(j.in));   // tsq_threads.cpp:714-717
+            return false;
+        }
         uint8_t header[16];
-        if (src.read_at(0, 16, header) != 16 || memcmp(header, "TSQ1", 4) != 0) return false;   // tsq_threads.cpp:732-752
+        if (src.read_at(0, 16, header) != 16 || memcmp(header, "TSQ1", 4) != 0) {              // tsq_threads.cpp:732-752
+            if (verbose_) printf("Error: signature mismatch (expected TSQ1).\n");
+            return false;
+        }
         uint32_t nb; uint64_t total;
         memcpy(&nb, header + 4, 4); memcpy(&total, header + 8, 8);
-        if (nb == 0) return false;                                                             // tsq_threads.cpp:759-768
+        if (nb == 0) {                                                                         // tsq_threads.cpp:759-768
+            if (verbose_) printf("Error: no blocks to decode in input file.\n");
+            return false;
+        }
         // The header is not trusted with an allocation before it has been held against the container: a frame is at
         // least 6 bytes, a block at most 4 MiB, and no stream expands more than 64x (eight 64-byte copies per 13-byte group).
         if ((uint64_t)nb > (src.size - 16) / 6) return false;
@@ -739,7 +807,8 @@ private:
             if (!ok) break;
             if (bn == 0) { ok = false; break; }                        // truncated container
             // the result buffer is made resident only now that a first batch of frames has been found well formed
-            if (!touching && (sink.mapped || !stage_out)) { touch.start(sink.mem, (size_t)total, sink.mapped ? sink.map_fd : -1); touching = true; }
+            if (!touching && sink.mapped) { touch.start_mapped([&sink](size_t upto) { return sink.ensure_allocated(upto); }, [&sink] { return sink.cursor.load(); }, (size_t)total); touching = true; }
+            if (!touching && !stage_out) { touch.start(sink.mem, (size_t)total); touching = true; }
             // the batch's frames are one contiguous slice of the container: the lane's device feeder reads it (file sources), copies
             // it to the device and launches the kernels
             Issued* flag = issued_[lane_i].get();
@@ -770,7 +839,7 @@ private:
         }
         close_drainer();                                              // (drains what is in flight first)
         for (auto& l : lanes_) { (void)hipSetDevice(l.dev->device); (void)hipStreamSynchronize(l.dev->stream); }
-        touch.join();                                                 // nobody may still be touching the buffer when it is freed
+        touch.cancel();                                               // nobody may still be touching (or allocating behind) the buffer when it is freed
         if (ok && produced != total) ok = false;
         if (!sink.finish()) ok = false;
         if (!j.outfile) {
@@ -876,6 +945,9 @@ extern "C" void tsqInit(struct TSQCompressionContext* ctx)
     if (ctx && ctx->refhash) memset(ctx->refhash, 0, TSQ_HASH_SZ);    // tsq_context.cpp:77-80
 }
 
+static std::atomic<int> g_lookahead_state{0};
+extern "C" int tsqa_encode_lookahead_state(void) { return g_lookahead_state.load(); }
+
 extern "C" void tsqEncode(struct TSQCompressionContext* ctx, uint8_t* inputBlock, uint8_t* outputBlock,
                           uint32_t* outputSize, uint32_t inputSize, uint32_t withExtensions)
 {
@@ -895,11 +967,14 @@ extern "C" void tsqEncode(struct TSQCompressionContext* ctx, uint8_t* inputBlock
     // through process_vm_readv on this process, which stops at an unmapped page instead of faulting; what cannot be
     // read is seen as zeros (the canonical conditions after the last block).
     size_t halo = 0;
-    if (!getenv("TSQ_AMD_ENCODE_NO_LOOKAHEAD")) {
+    if (getenv("TSQ_AMD_ENCODE_NO_LOOKAHEAD")) g_lookahead_state = 3;
+    else {
         struct iovec to = { l.h_in + inputSize, kHalo }, from = { inputBlock + inputSize, kHalo };
         ssize_t got = process_vm_readv(getpid(), &to, 1, &from, 1, 0);
-        if (got > 0) halo = (size_t)got;
+        if (got > 0) { halo = (size_t)got; g_lookahead_state = 1; }
+        else if (got < 0 && errno == EFAULT) g_lookahead_state = 1;       // (the very next byte is unmapped: nothing to read, nothing refused)
         else if (got < 0 && (errno == EPERM || errno == ENOSYS)) {
+            g_lookahead_state = 2;
             // a seccomp profile or a sandbox refuses the call: the look-ahead is then ALWAYS seen as zeros, and a loop over the blocks
             // of one buffer no longer gives the container's streams at block edges.  Said once, not silently.
             static std::atomic<bool> said{false};

@@ -119,8 +119,8 @@ struct StageCfgT {
     static constexpr uint32_t total = WINDOW ? off_win + WIN + 32 : off_win;   // (without the window two blocks fit one CU)
     static_assert(total <= (WINDOW ? 160u : 80u) * 1024u, "LDS budget");
 };
-// ctl words: 0 queue head, 1 queue tail, 2 tiles with twin masks, 3 / 35 even / odd tiles matched, 4 / 15 even / odd tiles with orbits,
-//            5 tiles walked, 6 stop, 7..9 BUILDER/EMIT (tsq_enc_builder.cuh), 10..14 WALK/ACCOUNT events, 33 tiles committed, 34 tiles hashed,
+// ctl words: 0 queue head, 1 queue tail, 2 tiles with twin masks, 3 / 35 even / odd tiles matched, 10 / 15 even / odd tiles with orbits,
+//            4 events produced (WALK -> ACCOUNT) and 5 tiles walked: an aligned pair, ACCOUNT reads both with one 8-byte load, 6 stop, 7..9 BUILDER/EMIT (tsq_enc_builder.cuh), 10..14 WALK/ACCOUNT events, 33 tiles committed, 34 tiles hashed,
 // record: header words 2,3 = the lanes the parse visited (WALK)
 //         per-lane words, in four groups of four: group g of lane l is the 16-byte LDS word at ARR + g * 256 + l * 4, so that a stage
 //         reads or writes a whole group (or half of one) with ONE LDS instruction -- the LDS pipe is what all the wavefronts share,
@@ -137,10 +137,10 @@ __device__ __forceinline__ u32x4_t lds_ld4(volatile lds_u32_t* p) { return *(vol
 __device__ __forceinline__ u32x2_t lds_ld2(volatile lds_u32_t* p) { return *(volatile lds_u32x2_t*)p; }
 __device__ __forceinline__ void lds_st4(volatile lds_u32_t* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { u32x4_t v; v.x = a; v.y = b; v.z = c; v.w = d; *(volatile lds_u32x4_t*)p = v; }
 __device__ __forceinline__ void lds_st2(volatile lds_u32_t* p, uint32_t a, uint32_t b) { u32x2_t v; v.x = a; v.y = b; *(volatile lds_u32x2_t*)p = v; }
-// events between WALK and ACCOUNT, and their ctl words (10 events produced, 11 consumed, 12 queries answered, 13 the answer,
+// events between WALK and ACCOUNT, and their ctl words (4 events produced, 11 consumed, 12 queries answered, 13 the answer,
 // 14 the tile ACCOUNT works on: the tiles before it are accounted)
 enum : uint32_t { kEvSeg = 1, kEvHaz = 2, kEvEnd = 3 };
-enum : uint32_t { kCtlEvHead = 10, kCtlEvTail = 11, kCtlReplies = 12, kCtlReplyValue = 13, kCtlAccounted = 14, kCtlOrbitOdd = 15, kCtlCommitted = 33, kCtlHashed = 34, kCtlMatchedOdd = 35, kCtlNear = 36, kCtlIn = 37 };
+enum : uint32_t { kCtlEvHead = 4, kCtlOrbitEven = 10, kCtlEvTail = 11, kCtlReplies = 12, kCtlReplyValue = 13, kCtlAccounted = 14, kCtlOrbitOdd = 15, kCtlCommitted = 33, kCtlHashed = 34, kCtlMatchedOdd = 35, kCtlNear = 36, kCtlIn = 37 };
 
 // Instrumented builds time only the spin loops (and only when they actually spin): s_memtime costs a few
 // hundred cycles, so finer timing distorts the pipeline it measures.  busy = total - waited.
@@ -252,7 +252,7 @@ __device__ __forceinline__ void stage_publish(lds_u32_t* ctl, uint32_t word, uin
 // SCAN is two wavefronts: HASH loads the tile's input words, hashes them and runs the owner image (which lanes share a
 // bucket: a filter); TWINS turns that into the exact twin masks.
 template <bool WINDOW>
-__device__ __forceinline__ void stage_hash(const uint8_t* src, uint64_t avail, uint32_t n, lds_u8_t* lds, uint32_t lane)
+__device__ __forceinline__ void stage_hash(const uint8_t* src, uint64_t avail, uint32_t n, lds_u8_t* lds, uint32_t lane, const uint16_t* table = nullptr)
 {
     using StageCfg = StageCfgT<WINDOW>;
     volatile lds_u8_t* owner = lds + StageCfg::off_owner;
@@ -284,6 +284,10 @@ __device__ __forceinline__ void stage_hash(const uint8_t* src, uint64_t avail, u
         TSQ_TRACE(0, t);
         const uint32_t h = hash4(w16.x);
         const uint32_t hf = StageCfg::fold(h);
+#ifdef TSQ_X_TBL_PREFETCH
+        // the table line MATCH will gather from a few tiles from now is pulled into the L2 already (the value is not used)
+        if (!WINDOW || TSQ_X_TBL_PREFETCH > 1) { const uint32_t pf = table[h]; asm volatile("" :: "v"(pf)); }
+#endif
         // The owner image: per folded hash, the last lane that had it and the low two bits of its tile number.  Nothing is ever
         // retired: an entry is taken for what it says -- a lane one to four tiles back -- and TWINS checks it against that lane's own
         // hash: a lane that really owns the bucket has this folded hash; the zero the image starts with and entries older than four
@@ -549,7 +553,14 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         //      wavefronts of a workgroup share the vector L1): gather from it right away, without waiting for the parser ...
         if (t >= LM + 1u && !stage_wait_seen(ctl, kCtlCommitted, t - LM, committed_seen, 3)) break;
         TSQ_TRACE(10, t);
+#ifdef TSQ_X_EXTRA_GATHER   // perturbation (streams unchanged): a second, equally cold gather per lane -- what the table's line traffic costs shows as the slowdown
+        const uint32_t tv_extra = table[h ^ 0x1AAAAu];
+#endif
+#ifdef TSQ_X_FAKE_TABLE   // timing only (wrong streams): every gather hits 512 bytes of the table
+        const uint32_t tv_old = table[h & 0xFFu];
+#else
         const uint32_t tv_old = table[h];                // (a plain load: an atomic one is waited for on the spot, and the gather's latency must stay hidden)
+#endif
         MREG_END(12);
         MREG_BEGIN(11);
         // ... and bring the entries up to "visits of tiles <= t-LM" once the parser has finished tile t-LM: a lane with a
@@ -578,6 +589,12 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         // ---- candidates of tile t
         const uint32_t p = (t << 6) + lane;
         const uint32_t cand0 = candidate_of(tv, p);
+#ifdef TSQ_X_EXTRA_GATHER
+        asm volatile("" :: "v"(tv_extra));
+#endif
+#ifdef TSQ_X_EXTRA_CAND      // perturbation: a second 16-byte gather per lane from a cold line of the input window
+        { const uint4 xb = ld128z(src, (uint64_t)((cand0 ^ 0x5555u) & 0x3FFFFFu) < avail ? (cand0 ^ 0x5555u) & 0x3FFFFFu : 0u, avail); asm volatile("" :: "v"(xb.x), "v"(xb.y), "v"(xb.z), "v"(xb.w)); }
+#endif
         MREG_BEGIN(13);
         // their 16 bytes come from the window ring in LDS (SCAN has written everything below (t+1)*64); the few lanes whose
         // candidate ends beyond that (closer than 19 bytes to the tile's end) gather from global memory
@@ -591,7 +608,12 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
             cb = make_uint4(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
                             __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh));
             if (cand0 + 19u > ((t + 1u) << 6) || p - cand0 > 65536u) cb = ld128z(src, cand0, avail);
-        } else cb = ld128z(src, cand0, avail);          // the lean layout (two blocks per CU) has no window: gather from L2
+        }
+#ifdef TSQ_X_FAKE_CAND    // timing only (wrong streams): candidate bytes from the lane's own position (the line HASH loaded) -- what do the candidate gathers cost?
+        else cb = ld128z(src, p, avail);
+#else
+        else cb = ld128z(src, cand0, avail);          // the lean layout (two blocks per CU) has no window: gather from L2
+#endif
         uint32_t k0 = prefix16(w16, cb);
         MREG_END(13);
         MREG_BEGIN(14);
@@ -686,13 +708,18 @@ __device__ __forceinline__ void stage_commit(uint32_t n, uint16_t* table, lds_u8
                              ((uint64_t)uniform(__hip_atomic_load(&visw[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) << 32);
         const uint32_t p = (t << 6) + lane;
         // among equal hashes the highest visited lane must win: lanes with an earlier twin store afterwards ...
-        if (((vis & ~tw) >> lane) & 1ull) table[h] = (uint16_t)p;
+#ifdef TSQ_X_FAKE_TABLE
+#define TSQ_TBL(hh) ((hh) & 0xFFu)
+#else
+#define TSQ_TBL(hh) (hh)
+#endif
+        if (((vis & ~tw) >> lane) & 1ull) table[TSQ_TBL(h)] = (uint16_t)p;
         // ... one store per hash group: the highest visited lane of a group stores, its earlier twins are dropped unseen
         // (a block of equal bytes is ONE group of 64 lanes)
         uint64_t late = vis & tw;
         while (late) {
             const uint32_t top = msb64(late);
-            if (lane == top) table[h] = (uint16_t)p;
+            if (lane == top) table[TSQ_TBL(h)] = (uint16_t)p;
             late &= ~((uint64_t)rdlane(tin_lo, top) | ((uint64_t)rdlane(tin_hi, top) << 32) | (1ull << top));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the table stores are complete
@@ -822,7 +849,7 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
 #endif
         TSQ_TRACE(7, t);
         TSQ_DELAY(5);
-        stage_publish(ctl, parity ? kCtlOrbitOdd : 4u, t + 1u, lane);
+        stage_publish(ctl, parity ? kCtlOrbitOdd : kCtlOrbitEven, t + 1u, lane);
     }
 #ifdef TSQ_STATS
     if (blockIdx.x == 0 && lane == 0 && parity == 0u) { g_enc_stats[6] = st_[6] + st_[5]; g_enc_stats[7] = TSQ_TOTAL(); g_enc_stats[53] = st_[24]; g_enc_stats[54] = st_[25]; }
@@ -928,44 +955,44 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
 
     uint32_t wbase = 0;                // (t * 64) % WIN
     uint32_t rec_slot = 0;             // t % R
+    // the tile record's words (loop-carried: the next tile's are requested at the end of a tile)
+    uint32_t spanword, lane_word, nx, orb_lo, orb_hi, tin_lo, tin_hi, tp1_lo, tp1_hi, tp2r_lo, tp2r_hi, tp3r_lo = 0, tp3r_hi = 0, nearw, seen_v;
+    auto load_record = [&](volatile lds_u32_t* arr) {
+        const u32x4_t ga = lds_ld4(arr + kGA), gb = lds_ld4(arr + kGB), gc = lds_ld4(arr + kGC);      // three LDS instructions (four with LM = 4)
+        spanword = ga.x; lane_word = ga.y; orb_lo = ga.z; orb_hi = ga.w;
+        nearw = gb.x; tin_lo = gb.z; tin_hi = gb.w;
+        tp1_lo = gc.x; tp1_hi = gc.y; tp2r_lo = gc.z; tp2r_hi = gc.w;
+        if (LM == 4u) { const u32x2_t gd = lds_ld2(arr + kGD); tp3r_lo = gd.x; tp3r_hi = gd.y; }
+        nx = spanword >> 24;
+    };
+    seen_v = ((volatile lds_u32_t*)ctl)[kCtlOrbitEven];
+    load_record(recs + StageCfg::ARR + lane * 4u);
+    asm volatile("" ::: "memory");
     TSQ_BEGIN();
     for (uint32_t t = 0; done == 0u; ++t, wbase = wbase + 64u == StageCfg::WIN ? 0u : wbase + 64u, rec_slot = rec_slot + 1u == StageCfg::R ? 0u : rec_slot + 1u) {
         const uint32_t base = t << 6;
-        uint64_t vall = 0, Vtail = 0;
+        uint64_t vall = 0;
         // (the walk always enters the tile: a symbol spans at most 64 positions, so v <= base - 1 + 64 here -- no test, a branch costs
         //  the serial stage as much as five instructions whether it is taken or not)
         {
             REG_BEGIN(0); REG_END(0);
             REG_BEGIN(1);
             // (the serial stage polls without sleeping: a wake-up from s_sleep costs it up to 64 cycles per hand-off)
-            const uint32_t orbit_word = (t & 1u) ? kCtlOrbitOdd : 4u;
+            const uint32_t orbit_word = (t & 1u) ? kCtlOrbitOdd : kCtlOrbitEven;
             volatile lds_u32_t* arr = recs + rec_slot * StageCfg::REC_WORDS + StageCfg::ARR + lane * 4u;
-            uint32_t spanword, lane_word, nx, orb_lo, orb_hi, tin_lo, tin_hi, tp1_lo, tp1_hi, tp2r_lo, tp2r_hi, tp3r_lo = 0, tp3r_hi = 0, nearw;
-            auto load_record = [&]() {
-                const u32x4_t ga = lds_ld4(arr + kGA), gb = lds_ld4(arr + kGB), gc = lds_ld4(arr + kGC);      // three LDS instructions (four with LM = 4)
-                spanword = ga.x; lane_word = ga.y; orb_lo = ga.z; orb_hi = ga.w;
-                nearw = gb.x; tin_lo = gb.z; tin_hi = gb.w;
-                tp1_lo = gc.x; tp1_hi = gc.y; tp2r_lo = gc.z; tp2r_hi = gc.w;
-                if (LM == 4u) { const u32x2_t gd = lds_ld2(arr + kGD); tp3r_lo = gd.x; tp3r_hi = gd.y; }
-                nx = spanword >> 24;
-            };
-            // The counter and the record's words are requested together: the LDS serves a wavefront's requests in order, so when the
-            // counter (asked for first) says the record is there, the words that came back behind it are the record's; only when it is
-            // not there yet (the lag loop is late) are they asked for again.  One LDS round trip per tile less on the serial stage.
-            {
-                const uint32_t seen_v = ((volatile lds_u32_t*)ctl)[orbit_word];
-                load_record();
-                asm volatile("" ::: "memory");
-                if (uniform(seen_v) < t + 1u) {
+            // The counter and the record's words were requested together at the end of the previous tile (in front of its publication's
+            // bookkeeping): the LDS serves a wavefront's requests in order, so when the counter (asked for first) says the record is
+            // there, the words that came back behind it are the record's; only when it was not there yet (the lag loop is late) are they
+            // asked for again.
+            if (uniform(seen_v) < t + 1u) {
 #ifdef TSQ_STATS
-                    const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
+                const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
 #endif
-                    while (!stage_ready(ctl, orbit_word, t + 1u)) { TSQ_SPIN(ctl); }
+                while (!stage_ready(ctl, orbit_word, t + 1u)) { TSQ_SPIN(ctl); }
 #ifdef TSQ_STATS
-                    st_[8] += __builtin_amdgcn_s_memtime() - w0_;
+                st_[8] += __builtin_amdgcn_s_memtime() - w0_;
 #endif
-                    load_record();
-                }
+                load_record(arr);
             }
             TSQ_CNT(15, 1);
             TSQ_TRACE(8, t);
@@ -1138,7 +1165,6 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                 if (L >= 64u || done != 0u) break;
                 segment();
             }
-            Vtail = vall & ~handed;
         }
         // ---- the tile's last segment goes to ACCOUNT, its visited mask to MATCH and COMMIT (they patch / commit the table), and the
         //      tile counter moves on: four stores of lane 0 in one stretch (the LDS executes them in this order)
@@ -1151,8 +1177,14 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
             __hip_atomic_store(&vis[lane & 1u], (lane & 1u) ? (uint32_t)(vall >> 32) : (uint32_t)vall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         TSQ_DELAY(6);
+        // (no event for the tile's last segment: ACCOUNT takes it from the visited mask above once this counter says the tile is walked)
         stage_publish(ctl, 5, t + 1u, lane);
-        if (Vtail != 0ull) ev_push(kEvSeg, base, (uint32_t)Vtail, (uint32_t)(Vtail >> 32));
+        {   // the next tile's record is requested now: its words travel while the loop's bookkeeping runs
+            const uint32_t next_slot = rec_slot + 1u == StageCfg::R ? 0u : rec_slot + 1u;
+            seen_v = ((volatile lds_u32_t*)ctl)[(t & 1u) ? kCtlOrbitEven : kCtlOrbitOdd];
+            load_record(recs + next_slot * StageCfg::REC_WORDS + StageCfg::ARR + lane * 4u);
+            asm volatile("" ::: "memory");
+        }
 #ifdef TSQ_STATS
         if (lane == 0) ctl[40u + (t & 7u)] = (uint32_t)__builtin_amdgcn_s_memtime();       // (the lag loop is timed from here)
 #endif
@@ -1285,96 +1317,101 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
         }
     };
 
-    TSQ_BEGIN();
-    for (;;) {
-        uint32_t kind, ea, eb, ec;
-        {
-            // the producer's counter and the event's words are requested together (the LDS serves a wavefront's requests in order: if
-            // the counter says the event is there, the words behind it are the event's): ACCOUNT is the busiest wavefront of the
-            // pipeline, and this is one LDS round trip per event less
-            volatile lds_u32_t* e = evq + (ev_tail % StageCfg::EQ) * StageCfg::EV_WORDS;
-            const uint32_t hv = ((volatile lds_u32_t*)ctl)[kCtlEvHead];
-            uint32_t w = e[lane & 3u];
-            asm volatile("" ::: "memory");
-            if (uniform(hv) < ev_tail + 1u) {
-#ifdef TSQ_STATS
-                const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
-#endif
-                while (!stage_ready(ctl, kCtlEvHead, ev_tail + 1u)) { TSQ_SPIN(ctl); __builtin_amdgcn_s_sleep(1); }
-#ifdef TSQ_STATS
-                st_[8] += __builtin_amdgcn_s_memtime() - w0_;
-#endif
-                w = e[lane & 3u];
-            }
-            kind = rdlane(w, 0); ea = rdlane(w, 1); eb = rdlane(w, 2); ec = rdlane(w, 3);
-            ev_tail++;
-            __hip_atomic_store(&ctl[kCtlEvTail], ev_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        if (kind == kEvEnd) break;
-        const uint32_t ev_base = ea & ~63u;
-        const uint32_t new_tile = ev_base != base ? 1u : 0u;
-        // the tile's record: its class words (a later segment of a tile that a query opened reads the record again: WALK patches the
-        // hazard lanes it decides itself into the class words, and it has done so for every lane of a segment before the segment's event)
-        auto open_tile = [&]() {
-            base = ev_base;
-            const uint32_t t = base >> 6;
-            volatile lds_u32_t* arr = recs + (t % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::ARR + lane * 4u;
-            const u32x2_t ga = lds_ld2(arr + kGA);
-            const uint32_t spanword = ga.x, fresh_lw = ga.y;
-            lw = ((qmask >> lane) & 1ull) ? lw : fresh_lw;            // (a lane a query decided keeps the candidate ACCOUNT gave it)
-            span_nat = spanword & 0xFFu;
-            certain_m = __ballot((spanword & 0x400u) != 0u);
-            // (SCAN may reuse the records of the tiles before this one)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __hip_atomic_store(&ctl[kCtlAccounted], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            TSQ_DELAY(7);
-            TSQ_CNT(15, 1);
-        };
-        auto account_segment = [&]() {
-            // ---- the segment's effect on the symbol state, O(1) from its masks.  `dsym` symbols close (matches and
-            //      the literal runs in front of them); the state afterwards hangs on the last match.
-            const uint64_t V = (uint64_t)eb | ((uint64_t)ec << 32);
-            const uint64_t M = V & certain_m, N = V ^ M;
-            const uint32_t L0 = s_lsb64(V);
-            const uint32_t has_m = s_nz64(M);
-            const uint32_t Le = s_msb64(V | 1ull), Lm = s_msb64(M | 1ull);
-            const uint32_t first_isN = (uint32_t)(N >> L0) & 1u;                // L0 is the lowest lane of V
-            uint64_t r = N & (N >> 1); r &= r >> 2; r &= r >> 4; r &= r >> 8;     // a literal run of 16 or more inside
-            const uint32_t run_end = base + s_sel(has_m, s_lsb64(M | (1ull << 63)), Le + 1u);
-            const uint32_t chunk = s_ge(run_end - lit_from, 16u) & first_isN;     // the entry run completes a 16-byte chunk
-            if (__builtin_expect(s_nz64(r) | chunk, 0)) { TSQ_CNT(28, 1); replay_segment(V); }
-            else {
-                const uint32_t e_pos = base + L0, lm_pos = base + Lm, endm = lm_pos + rdlane(span_nat, Lm);
-                const uint32_t last_m = s_eq(Le, Lm) & has_m;
-                const uint32_t pre = s_lt(lit_from, e_pos) & (first_isN ^ 1u);      // a pending literal closes in front of an entry match
-                const uint32_t dsym = (uint32_t)__builtin_popcountll(M) + (uint32_t)__builtin_popcountll(M & (N << 1)) + pre;
-                const uint32_t nsym_n = nsym + s_sel(has_m, dsym, 0u);
-                const uint32_t origin_n = s_sel(has_m, s_sel(nsym_n & 1u, lm_pos, endm), origin);
-                const uint32_t new_run = s_sel(has_m, last_m ^ 1u, am);              // a literal run starts inside / at the entry of the segment
-                run0 = s_sel(new_run, s_sel(has_m, endm, e_pos), run0);
-                origin_r0 = s_sel(new_run, origin_n, origin_r0);
-                odd_r0 = s_sel(new_run, nsym_n & 1u, odd_r0);
-                lit_from = s_sel(has_m, endm, lit_from);
-                am = last_m;
-                nsym = nsym_n;
-                origin = origin_n;
-            }
-            Vt |= V; Mt |= M;
-        };
-        // (the usual event -- a tile's one segment -- has a straight path of its own: a branch costs a wavefront 25 cycles)
-        if (__builtin_expect((kind == kEvSeg ? new_tile : 0u) != 0u, 1)) {
-            flush_pending(); qmask = 0;
-            open_tile();
-            account_segment();
-            continue;
-        }
-        if (new_tile | (kind == kEvSeg ? 1u : 0u)) {
-            // ---- a new tile: what is pending goes to the builder, then the tile's record
-            if (new_tile) { flush_pending(); qmask = 0; }
-            open_tile();
-        }
-        if (kind == kEvSeg) account_segment();
+    // WALK's progress reaches ACCOUNT two ways.  A tile's visited lanes: the mask in the tile's record once the "tiles walked" counter
+    // has passed the tile (no event: the serial stage stores the mask for MATCH and COMMIT anyway).  Queries, each preceded by the lanes
+    // visited so far in its tile (kEvSeg), through the event ring.  WALK pushes a tile's events before it publishes the tile, so: an
+    // event of the tile at hand comes first; any other event means the tile at hand is complete.  The event counter and the tile
+    // counter are read with ONE 8-byte load (a consistent pair), and the next event's words, the tile's mask and its class words are
+    // requested in the same breath (the LDS serves a wavefront's requests in order: what comes back behind a counter that says "there"
+    // is there) -- one LDS round trip per tile on this wavefront.
+    uint32_t cur = 0, cur_slot = 0;           // the tile at hand and its record
+    uint64_t got = 0;                         // its lanes already accounted: segments in front of queries, and the query lanes
+    uint32_t opened = 0;                      // an event has opened it already
+    // the tile's record: its class words (a later segment of a tile that a query opened takes the words again: WALK patches the
+    // hazard lanes it decides itself into the class words, and it has done so for every lane of a segment before the segment's event
+    // or the tile counter)
+    auto open_tile = [&](const u32x2_t ga) {
+        base = cur << 6;
+        const uint32_t spanword = ga.x, fresh_lw = ga.y;
+        lw = ((qmask >> lane) & 1ull) ? lw : fresh_lw;            // (a lane a query decided keeps the candidate ACCOUNT gave it)
+        span_nat = spanword & 0xFFu;
+        certain_m = __ballot((spanword & 0x400u) != 0u);
+        TSQ_DELAY(7);
+        TSQ_CNT(15, 1);
+    };
+    auto account_segment = [&](const uint64_t V) {
+        // ---- the segment's effect on the symbol state, O(1) from its masks.  `dsym` symbols close (matches and
+        //      the literal runs in front of them); the state afterwards hangs on the last match.
+        const uint64_t M = V & certain_m, N = V ^ M;
+        const uint32_t L0 = s_lsb64(V);
+        const uint32_t has_m = s_nz64(M);
+        const uint32_t Le = s_msb64(V | 1ull), Lm = s_msb64(M | 1ull);
+        const uint32_t first_isN = (uint32_t)(N >> L0) & 1u;                // L0 is the lowest lane of V
+        uint64_t r = N & (N >> 1); r &= r >> 2; r &= r >> 4; r &= r >> 8;     // a literal run of 16 or more inside
+        const uint32_t run_end = base + s_sel(has_m, s_lsb64(M | (1ull << 63)), Le + 1u);
+        const uint32_t chunk = s_ge(run_end - lit_from, 16u) & first_isN;     // the entry run completes a 16-byte chunk
+        if (__builtin_expect(s_nz64(r) | chunk, 0)) { TSQ_CNT(28, 1); replay_segment(V); }
         else {
+            const uint32_t e_pos = base + L0, lm_pos = base + Lm, endm = lm_pos + rdlane(span_nat, Lm);
+            const uint32_t last_m = s_eq(Le, Lm) & has_m;
+            const uint32_t pre = s_lt(lit_from, e_pos) & (first_isN ^ 1u);      // a pending literal closes in front of an entry match
+            const uint32_t dsym = (uint32_t)__builtin_popcountll(M) + (uint32_t)__builtin_popcountll(M & (N << 1)) + pre;
+            const uint32_t nsym_n = nsym + s_sel(has_m, dsym, 0u);
+            const uint32_t origin_n = s_sel(has_m, s_sel(nsym_n & 1u, lm_pos, endm), origin);
+            const uint32_t new_run = s_sel(has_m, last_m ^ 1u, am);              // a literal run starts inside / at the entry of the segment
+            run0 = s_sel(new_run, s_sel(has_m, endm, e_pos), run0);
+            origin_r0 = s_sel(new_run, origin_n, origin_r0);
+            odd_r0 = s_sel(new_run, nsym_n & 1u, odd_r0);
+            lit_from = s_sel(has_m, endm, lit_from);
+            am = last_m;
+            nsym = nsym_n;
+            origin = origin_n;
+        }
+        Vt |= V; Mt |= M;
+    };
+
+    TSQ_BEGIN();
+    uint32_t kind, ea, eb, ec, walked, has_ev, ev_is_cur;
+    u32x2_t ga;
+    uint32_t vw;
+    // counters, next event, the tile's visited mask and class words in one breath; waits until there is an event or a walked tile
+    auto snapshot = [&]() {
+        for (;;) {
+            volatile lds_u32_t* const e = evq + (ev_tail % StageCfg::EQ) * StageCfg::EV_WORDS;
+            volatile lds_u32_t* const rec = recs + cur_slot * StageCfg::REC_WORDS;
+            const u32x2_t hw = lds_ld2((volatile lds_u32_t*)ctl + kCtlEvHead);      // [4] events produced, [5] tiles walked
+            const uint32_t w = e[lane & 3u];
+            vw = rec[2u + (lane & 1u)];
+            ga = lds_ld2(rec + StageCfg::ARR + lane * 4u + kGA);
+            asm volatile("" ::: "memory");
+            has_ev = uniform(hw.x) != ev_tail ? 1u : 0u;
+            walked = uniform(hw.y);
+            kind = rdlane(w, 0); ea = rdlane(w, 1);
+            ev_is_cur = has_ev & (kind != kEvEnd ? 1u : 0u) & ((ea >> 6) == cur ? 1u : 0u);
+            if (__builtin_expect((has_ev | (walked != cur ? 1u : 0u)) != 0u, 1)) { eb = rdlane(w, 2); ec = rdlane(w, 3); return; }
+#ifdef TSQ_STATS
+            const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
+#endif
+            TSQ_SPIN(ctl); __builtin_amdgcn_s_sleep(1);
+#ifdef TSQ_STATS
+            st_[8] += __builtin_amdgcn_s_memtime() - w0_ + 60u;
+#endif
+        }
+    };
+    auto handle_event = [&]() {
+        // ---- an event of the tile at hand
+        ev_tail++;
+        __hip_atomic_store(&ctl[kCtlEvTail], ev_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((opened ^ 1u) | (kind == kEvSeg ? 1u : 0u)) {
+            if (opened == 0u) qmask = 0;
+            open_tile(ga);
+            opened = 1;
+        }
+        if (kind == kEvSeg) {
+            const uint64_t V = (uint64_t)eb | ((uint64_t)ec << 32);
+            account_segment(V);
+            got |= V;
+        } else {
             const uint32_t i = ea, cand = eb;
             uint32_t k = ec & 0xFFu;
             const uint32_t L = i - base;
@@ -1439,7 +1476,26 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
             TSQ_LDS_RELEASE();
             n_reply++;
             __hip_atomic_store(&ctl[kCtlReplies], n_reply, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            got |= bit;
         }
+        };
+    for (;;) {
+        snapshot();
+        // (a tile's events -- queries and the lanes visited in front of them -- are rare; the usual tile goes straight through below)
+        while (__builtin_expect(ev_is_cur != 0u, 0)) { handle_event(); snapshot(); }
+        if (walked == cur) break;                     // nothing walked is left and the next event is not this tile's: kEvEnd
+        // ---- the tile at hand is complete: its remaining visited lanes are its last segment
+        const uint64_t vis = (uint64_t)rdlane(vw, 0) | ((uint64_t)rdlane(vw, 1) << 32);
+        const uint64_t V = vis & ~got;
+        qmask = opened ? qmask : 0ull;
+        open_tile(ga);
+        if (V != 0ull) account_segment(V);
+        flush_pending();                              // the tile's item goes to the builder
+        cur++;
+        cur_slot = cur_slot + 1u == StageCfg::R ? 0u : cur_slot + 1u;
+        got = 0; opened = 0;
+        // (SCAN may reuse the records of the tiles before `cur`: everything ACCOUNT needs of them is in registers or in the queue)
+        __hip_atomic_store(&ctl[kCtlAccounted], cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     flush_pending();
 #ifdef TSQ_STATS
@@ -1506,7 +1562,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void enc
     if (role == kRoleWalk) stage_walk<EXT, WINDOW>(src, avail, n, lds3, lane);
     else if (role == kRoleAccount) stage_account<EXT, WINDOW>(n, lds3, lane);
     else if (role == kRoleCommit) stage_commit<WINDOW>(n, table, lds3, lane);
-    else if (role == kRoleHash) stage_hash<WINDOW>(src, avail, n, lds3, lane);
+    else if (role == kRoleHash) stage_hash<WINDOW>(src, avail, n, lds3, lane, table);
     else if (role == kRoleTwins) stage_twins<WINDOW>(n, lds3, lane);
     else if (role == kRoleIn) stage_in<WINDOW>(n, lds3, lane);
     else if (role == kRoleNear) stage_near<EXT, WINDOW>(n, lds3, lane);

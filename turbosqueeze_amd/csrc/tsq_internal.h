@@ -27,6 +27,7 @@ struct tsqa_ctx {
     std::vector<uint64_t> host_frame_src;      // where each owned frame's stream starts in the host container
     hipEvent_t host_frames_copied = nullptr;   // recorded behind the descriptors' copy to the device
     bool host_frames_pending = false;
+    uint32_t sharded_n_local = 0;              // frames of the last tsqa_sharded_fetch_decode_async (tsqa_sharded_decode_again_async)
     char probe_shape[160] = {0};               // what tsqa_measure_copy chose (tsqa_copy_probe_shape)
     uint32_t* duo_ring = nullptr;      // two-workgroup decoder: chunk records handed from the PARSE to the COPY workgroup of a block
     uint32_t* duo_flags = nullptr;     // and their progress counters

@@ -313,8 +313,9 @@ extern "C" int tsqa_compress_device(tsqa_ctx* c, const void* d_in, size_t n, voi
     return status_to_rc(c, st, "compress");
 }
 
-extern "C" int tsqa_decompress_device_async(tsqa_ctx* c, const void* d_in, size_t n, uint32_t n_blocks, void* d_out,
-                                            size_t out_cap, uint64_t* d_out_size, int32_t* d_status, void* hip_stream)
+// (variant < 0: the context's decode variant; the retry after TSQA_ERR_STALL passes 4 without touching the context's setting)
+static int decompress_device_async_impl(tsqa_ctx* c, const void* d_in, size_t n, uint32_t n_blocks, void* d_out,
+                                        size_t out_cap, uint64_t* d_out_size, int32_t* d_status, void* hip_stream, int variant)
 {
     if (!c) return TSQA_ERR_ARG;
     if (!d_in || !d_out || !d_out_size || !d_status || n < 16 || n_blocks == 0) { c->set_error("decompress: bad argument"); return TSQA_ERR_ARG; }
@@ -326,9 +327,15 @@ extern "C" int tsqa_decompress_device_async(tsqa_ctx* c, const void* d_in, size_
     const bool timed = c->prof_begin(3, s);
     hipLaunchKernelGGL(frame_walk_kernel, dim3(1), dim3(64), 0, s, static_cast<const uint8_t*>(d_in), (uint64_t)n, n_blocks,
                        (uint64_t)out_cap, c->frames, d_out_size, d_status);
-    rc = c->launch_decode(d_in, n_blocks, d_out, d_status, s);
+    rc = c->launch_decode(d_in, n_blocks, d_out, d_status, s, variant);
     if (timed) c->prof_end(3, s);
     return rc;
+}
+
+extern "C" int tsqa_decompress_device_async(tsqa_ctx* c, const void* d_in, size_t n, uint32_t n_blocks, void* d_out,
+                                            size_t out_cap, uint64_t* d_out_size, int32_t* d_status, void* hip_stream)
+{
+    return decompress_device_async_impl(c, d_in, n, n_blocks, d_out, out_cap, d_out_size, d_status, hip_stream, -1);
 }
 
 // ---- sharded operation: a device owns some of a job's blocks ----
@@ -388,10 +395,7 @@ extern "C" int tsqa_decompress_device(tsqa_ctx* c, const void* d_in, size_t n, v
     if (st == kErrStall) {
         // a workgroup of a several-workgroups-per-block decode did not get onto the GPU in time (other work held the CUs): the
         // container is not at fault -- once more with one workgroup per block, which waits for nobody
-        const int keep = c->dec_variant;
-        c->dec_variant = 4;
-        rc = tsqa_decompress_device_async(c, d_in, n, nb, d_out, out_cap, c->d_size, c->d_status, s);
-        c->dec_variant = keep;
+        rc = decompress_device_async_impl(c, d_in, n, nb, d_out, out_cap, c->d_size, c->d_status, s, 4);
         if (rc) return rc;
         TSQ_HIP(c, hipMemcpyAsync(&sz, c->d_size, sizeof(sz), hipMemcpyDeviceToHost, s));
         TSQ_HIP(c, hipMemcpyAsync(&st, c->d_status, sizeof(st), hipMemcpyDeviceToHost, s));
@@ -569,7 +573,22 @@ extern "C" int tsqa_sharded_fetch_decode_async(tsqa_ctx* c, const void* host_con
     TSQ_HIP(c, hipMemcpyAsync(c->frames, c->host_frames, (size_t)n_local * sizeof(FrameInfo), hipMemcpyHostToDevice, s));
     TSQ_HIP(c, hipEventRecord(c->host_frames_copied, s));
     c->host_frames_pending = true;
+    c->sharded_n_local = n_local;
     return c->launch_decode_frames(d_streams, c->frames, n_local, d_out, d_status, s);
+}
+
+// After *d_status of tsqa_sharded_fetch_decode_async came back TSQA_ERR_STALL: the owned frames and their descriptors are still on the
+// device -- decode them again with one workgroup per block (decode variant 4), which waits for nobody.  A GPU of a sharded job holds
+// few blocks, so its first attempt always takes the several-workgroups-per-block decoder; a busy GPU must not fail a valid container.
+extern "C" int tsqa_sharded_decode_again_async(tsqa_ctx* c, const void* d_streams, void* d_out, int32_t* d_status, void* hip_stream)
+{
+    if (!c) return TSQA_ERR_ARG;
+    if (!d_streams || !d_out || !d_status) { c->set_error("sharded_decode_again: null pointer"); return TSQA_ERR_ARG; }
+    if (c->sharded_n_local == 0) { c->set_error("sharded_decode_again: no sharded decode to repeat on this context"); return TSQA_ERR_ARG; }
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    (void)hipSetDevice(c->device);
+    TSQ_HIP(c, hipMemsetAsync(d_status, 0, sizeof(int32_t), s));
+    return c->launch_decode_frames(d_streams, c->frames, c->sharded_n_local, d_out, d_status, s, 4);
 }
 
 // ---- the second roofline denominator: what a plain device copy reaches on this GPU ----

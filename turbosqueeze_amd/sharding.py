@@ -263,11 +263,23 @@ class DeviceBlocks:
         """Frame walk, owned frames to the device, decode (tsqa_sharded_fetch_decode_async).  -> uncompressed size of the job."""
         if container_size > host.size:
             raise ValueError(f"container size {container_size} exceeds the host mapping ({host.size} B)")
+        self._last_out = d_out
         return self.codec.sharded_fetch_decode_async(host.ptr, container_size, layout.rank, layout.world, self.slots, d_out)
+
+    STALL = 7                                             # TSQA_ERR_STALL
 
     def sync(self):
         self.torch.cuda.synchronize(self.device)
         st = self.codec.status()
+        if st == self.STALL and getattr(self, "_last_out", None) is not None:
+            # A sibling workgroup of the several-workgroups-per-block decoder did not get onto the GPU in time (a GPU of a sharded job
+            # holds few blocks, so that decoder is always the first choice): the container is not at fault.  The frames are still
+            # on the device: once more on one workgroup per block, which waits for nobody.
+            self.stall_retries = getattr(self, "stall_retries", 0) + 1
+            self.codec.sharded_decode_again_async(self.slots, self._last_out)
+            self.torch.cuda.synchronize(self.device)
+            st = self.codec.status()
+        self._last_out = None
         if st:
             raise RuntimeError(f"device status {st}")
 
