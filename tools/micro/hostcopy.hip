@@ -49,6 +49,31 @@ int main()
         t0 = now(); hipHostUnregister(fresh); t1 = now();
         printf("hipHostUnregister: %.1f ms\n", (t1 - t0) * 1e3);
     }
+    // both directions at once, from two threads on two streams (what the _MT scheduler's feeder and drainer do): pageable against pinned
+    {
+        uint8_t* d2; hipMalloc(&d2, n);
+        hipStream_t s1, s2; hipStreamCreateWithFlags(&s1, hipStreamNonBlocking); hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+        uint8_t* pageable2 = (uint8_t*)malloc(n); memset(pageable2, 3, n);
+        uint8_t* pinned2; hipHostMalloc(&pinned2, n, hipHostMallocPortable); memset(pinned2, 4, n);
+        auto both = [&](uint8_t* up, uint8_t* down, const char* what) {
+            const size_t piece = n / 4;
+            for (int rep = 0; rep < 2; ++rep) {
+                double a0 = now();
+                std::thread ta([&] { for (int k = 0; k < 4; ++k) hipMemcpyAsync(d + k * piece, up + k * piece, piece, hipMemcpyHostToDevice, s1); hipStreamSynchronize(s1); });
+                std::thread tb([&] { for (int k = 0; k < 4; ++k) hipMemcpyAsync(down + k * piece, d2 + k * piece, piece, hipMemcpyDeviceToHost, s2); hipStreamSynchronize(s2); });
+                ta.join(); tb.join();
+                double a1 = now();
+                printf("H2D + D2H at once, %s: %.1f ms for 1e9 B each way = %.1f GB/s per direction\n", what, (a1 - a0) * 1e3, n / (a1 - a0) / 1e9);
+            }
+        };
+        both(pageable, pageable2, "pageable / pageable");
+        both(pinned, pinned2, "pinned / pinned");
+        both(pageable, pinned2, "pageable up / pinned down");
+        both(pinned, pageable2, "pinned up / pageable down");
+        hipHostRegister(pageable2, n, hipHostRegisterDefault);
+        both(pageable, pageable2, "pageable up / registered down");
+        hipHostUnregister(pageable2);
+    }
     printf("hardware threads: %u\n", std::thread::hardware_concurrency());
     return 0;
 }

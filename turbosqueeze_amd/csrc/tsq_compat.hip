@@ -22,6 +22,7 @@
 #include <sys/mman.h>
 #include <sys/uio.h>
 #include <unistd.h>
+#include <algorithm>
 #include <atomic>
 #include <cerrno>
 #include <chrono>
@@ -149,6 +150,12 @@ struct Prefault {
             }
         });
     }
+    // A malloc()ed result: its pages are touched by a few threads, in stripes dealt round-robin (stripe s by thread s % k) so that the
+    // FRONT of the buffer -- where the first batch lands -- is resident first; wait_front(upto) returns as soon as every stripe below
+    // `upto` has been touched (the whole buffer took 5.4 ms with contiguous shares, and the first copy back waited for all of it).
+    static constexpr size_t kStripe = size_t(2) << 20;
+    uint8_t* tp = nullptr; size_t tn = 0; unsigned tk = 0;
+    std::unique_ptr<std::atomic<size_t>[]> stripes_done;       // per thread: stripes it has finished
     void start(uint8_t* p, size_t n) {
         if (!p || n < (size_t(64) << 20)) return;
         {   // transparent huge pages where the system allows them on request: 2 MiB per fault instead of 4 KiB
@@ -156,13 +163,28 @@ struct Prefault {
             (void)madvise(reinterpret_cast<void*>(a0), (n - 4096) & ~size_t(4095), MADV_HUGEPAGE);
         }
         unsigned hw = std::thread::hardware_concurrency();
-        unsigned k = hw >= 32 ? 16 : hw >= 8 ? 4 : 1;
-        size_t per = ((n / k) + 4095) & ~size_t(4095);
-        for (unsigned i = 0; i < k; ++i) {
-            size_t a = per * i;
-            if (a >= n) break;
-            size_t len = n - a < per ? n - a : per;
-            th.emplace_back([p, a, len] { for (size_t o = 0; o < len; o += 4096) { volatile uint8_t* q = p + a + o; *q = *q; } });   // (keeps what is already there: the header)
+        const unsigned k = hw >= 32 ? 16 : hw >= 8 ? 4 : 1;
+        tp = p; tn = n; tk = k;
+        stripes_done.reset(new std::atomic<size_t>[k]);
+        for (unsigned i = 0; i < k; ++i) stripes_done[i] = 0;
+        const size_t n_stripes = (n + kStripe - 1) / kStripe;
+        for (unsigned i = 0; i < k; ++i)
+            th.emplace_back([this, p, n, k, i, n_stripes] {
+                for (size_t s = i; s < n_stripes; s += k) {
+                    const size_t a = s * kStripe, len = n - a < kStripe ? n - a : kStripe;
+                    for (size_t o = 0; o < len; o += 4096) { volatile uint8_t* q = p + a + o; *q = *q; }   // (keeps what is already there: the header)
+                    stripes_done[i].store(s / k + 1, std::memory_order_release);
+                }
+            });
+    }
+    // every page below p + upto has been touched (returns at once when nothing was started)
+    void wait_front(size_t upto) {
+        if (!tk) return;
+        if (upto > tn) upto = tn;
+        const size_t need = (upto + kStripe - 1) / kStripe;          // stripes 0 .. need-1
+        for (unsigned i = 0; i < tk; ++i) {
+            const size_t mine = need > i ? (need - i + tk - 1) / tk : 0;     // how many of them are thread i's
+            while (stripes_done[i].load(std::memory_order_acquire) < mine) std::this_thread::yield();
         }
     }
     // (the touching threads of a malloc'ed buffer run to completion; the allocator of a mapped file is told to stop)
@@ -490,13 +512,59 @@ private:
         }
         return batch;
     }
+    // The sizes of a job's batches, in order.  File jobs and jobs over several devices: equal batches (job_batch).  A memory-to-memory
+    // job on one device is paced by the link, not by the batch count, so its batches are RAMPED (tools/tsq_cli b with TSQ_AMD_DEBUG=1):
+    //   decompress  small first: nothing can come back before the first batch has gone up and been decoded, so the first batch is a
+    //               sixteenth of the job and the following ones grow by half -- the copy back starts after 3.5 ms instead of 6.5 and
+    //               then runs without a gap while the larger batches go up beside it (the link is full duplex);
+    //   compress    small last: every block takes the encoder's block latency from the moment its bytes are on the device, the job ends
+    //               with the last batch's frames coming back, so the last batch is the small one.
+    std::vector<uint32_t> job_batches(uint32_t nb, bool through_files, bool compress) const {
+        std::vector<uint32_t> out;
+        const uint32_t batch = job_batch(nb, through_files);
+        if (through_files || n_devices_ > 1 || nb < 64 || getenv("TSQ_AMD_NO_RAMP")) {
+            for (uint32_t b = 0; b < nb; b += batch) out.push_back(nb - b < batch ? nb - b : batch);
+            return out;
+        }
+        if (compress) {
+            // (a batch holds its lane for the encoder's whole block latency: no more batches than lanes, each half again as large as the
+            //  one after it)
+            const uint32_t k = (uint32_t)lanes_.size() < 2u ? 1u : (uint32_t)lanes_.size();
+            double w = 1.0, sum = 0.0;
+            std::vector<double> ws(k);
+            for (uint32_t i = 0; i < k; ++i) { ws[k - 1u - i] = w; sum += w; w *= 1.5; }
+            uint32_t left = nb;
+            for (uint32_t i = 0; i < k && left; ++i) {
+                uint32_t take = i + 1u == k ? left : (uint32_t)(nb * ws[i] / sum + 0.5);
+                if (take > left) take = left;
+                if (take > batch_blocks_) take = batch_blocks_;
+                if (take == 0u) take = 1u;
+                out.push_back(take);
+                left -= take;
+            }
+            while (left) { const uint32_t take = left < batch_blocks_ ? left : batch_blocks_; out.push_back(take); left -= take; }   // (more than lanes x 512 blocks)
+            return out;
+        }
+        uint32_t left = nb, size = nb / 16u < 8u ? 8u : nb / 16u;
+        while (left) {
+            uint32_t take = size < left ? size : left;
+            if (left - take < 8u) take = left;                    // (no crumbs)
+            if (take > batch_blocks_) take = batch_blocks_;
+            out.push_back(take);
+            left -= take;
+            size += size / 2u;
+        }
+        return out;
+    }
     // Blocks per device-to-host piece: progress is reported per block as its bytes land; a piece of a few blocks keeps
     // the copies large enough for the DMA engines (one 4 MiB block per copy costs about a third of the bandwidth).
     // (through staging -- a file on the output side -- the pieces are larger: each is copied to pinned memory while the one before
     //  it is written, and a piece's write wants tens of megabytes to be worth its threads)
     static uint32_t progress_piece(uint32_t n_blocks, bool staged = false) {
         if (staged && n_blocks >= 32) return n_blocks / 4;
-        return n_blocks >= 64 ? 8u : n_blocks >= 8 ? 2u : 1u;
+        // (a copy to pageable memory has a fixed cost of its own -- the runtime locks and unlocks the pages around it --: 8 MB pieces came
+        //  back at 17-26 GB/s where 32-64 MB pieces reach the link's 46-50)
+        return n_blocks >= 32 ? 16u : n_blocks >= 16 ? 8u : n_blocks;
     }
 
     void loop() {
@@ -559,7 +627,7 @@ private:
         // (a mapped output file takes its bytes through pinned staging and a CPU copy: a device copy straight into file-backed pages
         //  runs at a fraction of the link's rate)
         const bool stage_in = src.mem == nullptr, stage_out = sink.mem == nullptr || sink.mapped;
-        const uint32_t batch = job_batch(nb, stage_in || stage_out);
+        const std::vector<uint32_t> sizes = job_batches(nb, stage_in || stage_out, true);
         Marks mk; mk.at("compress: buffers opened");
         Prefault touch;
         if (sink.mapped) touch.start_mapped([&sink](size_t upto) { return sink.ensure_allocated(upto); }, [&sink] { return sink.cursor.load(); }, sink.cap);
@@ -575,7 +643,7 @@ private:
             if (sz < 16 || sz > l.out_cap) { ok = false; return; }
             // (a mapped file is populated from its start while the batches land: nothing to wait for; a malloc'ed buffer is touched in
             //  one share per thread and must be complete)
-            if (!stage_out) { touch.join(); mk.at("compress: output pages touched"); }
+            if (!stage_out) { touch.wait_front(sink.at + sz); mk.at("compress: output pages touched"); }
             // The frames come back in pieces of a few blocks, in block order, and every block reports progress as soon as
             // its bytes have landed (tsq_threads.cpp:226-254: the writer emits a frame, then calls progress_cb).
             const uint64_t* fat = l.h_frame_at;                       // frame offsets inside the batch container
@@ -609,8 +677,8 @@ private:
             mk.at("compress: D2H done");
         };
 
-        for (uint32_t b0 = 0, k = 0; b0 < nb && ok; b0 += batch, ++k) {
-            const uint32_t bn = nb - b0 < batch ? nb - b0 : batch;
+        for (uint32_t b0 = 0, k = 0; b0 < nb && ok; b0 += sizes[k], ++k) {
+            const uint32_t bn = sizes[k];
             const size_t lane_i = k % lanes_.size();
             while (ok && fly.size() >= lanes_.size()) drain_one();
             if (!ok) break;
@@ -696,6 +764,7 @@ private:
         uint32_t done_blocks = 0;
         const bool stage_in = src.mem == nullptr, stage_out = sink.mem == nullptr || sink.mapped;
         const uint32_t batch = job_batch(nb, stage_in || stage_out);
+        const std::vector<uint32_t> sizes = job_batches(nb, stage_in || stage_out, false);
         Prefault touch;
         bool touching = false;
         auto drain = [&](const InFlight& f) {
@@ -718,8 +787,8 @@ private:
             mk.at("decompress: kernels done");
             // the blocks come back in pieces of a few blocks, in order; each block reports progress once it has landed
             // (tsq_threads.cpp:648-655: the writer copies a block out, then calls progress_cb)
-            if (!stage_out) { touch.join(); mk.at("decompress: output pages touched"); }
             uint8_t* dst = stage_out ? nullptr : sink.claim(f.out_bytes);
+            if (!stage_out && dst) { touch.wait_front((size_t)(dst - sink.mem) + f.out_bytes); mk.at("decompress: output pages touched"); }
             if (!stage_out && !dst) { ok = false; return; }
             const FrameInfo* fr = l.h_frames;
             const uint32_t piece = progress_piece(f.n_blocks, stage_out);
@@ -784,7 +853,8 @@ private:
             if (!ok) break;
             Lane& l = lanes_[lane_i];
             // sized by what is left of the job, not by the configured batch (a one-block container must not reserve gigabytes)
-            const uint32_t want_blocks = nb - b0 < batch ? nb - b0 : batch;
+            const uint32_t sched = k < sizes.size() ? sizes[k] : batch;
+            const uint32_t want_blocks = nb - b0 < sched ? nb - b0 : sched;
             size_t in_budget = (size_t)want_blocks * (3 + kSlotSize);
             if (in_budget > src.size - at) in_budget = src.size - at;
             if (!l.reserve(in_budget + 16, (size_t)want_blocks * kBlockSize + 256, want_blocks, stage_in, stage_out)) { ok = false; break; }
