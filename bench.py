@@ -264,6 +264,8 @@ def main():
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the extra weak-scaling measurement")
     ap.add_argument("--no-throughput", action="store_true", help="N = 1: skip the extra chip-filling measurement (4 GiB of the same text = 1 024 blocks)")
     ap.add_argument("--throughput-size", type=int, default=4 << 30)
+    ap.add_argument("--kind", default="text", choices=["text", "zeros", "random", "mix"],
+                    help="the job's synthetic input: enwik9-shaped text (the headline), or one of BASELINE config 5's inputs")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the extra sections (the other level, config 5's inputs, the host-gather step)")
     ap.add_argument("--config5-size", type=int, default=1 << 30)
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = production, 1 = serial baselines, 5 = round 2's encoder from the A/B library)")
@@ -290,13 +292,23 @@ def main():
 
     n = args.size
     nb = (n + tsq.BLOCK_SZ - 1) // tsq.BLOCK_SZ
+
+    def make_input(m, seed):
+        if args.kind == "zeros":
+            return np.zeros(m, dtype=np.uint8)
+        if args.kind == "random":
+            return tsq.synth.random_bytes(m, seed)
+        if args.kind == "mix":
+            return tsq.synth.mix(m, seed)
+        return tsq.synth.text(m, seed=seed)
+    kind_name = {"text": "enwik9-shaped synthetic text", "zeros": "zeros", "random": "random bytes", "mix": "50 % mix (64 KiB chunks random / text)"}[args.kind]
     codec = tsq.DeviceCodec(local_rank, ab=args.variant == 5)
     codec.set_variant(args.variant, args.variant if args.variant in (0, 1) else 0)
 
     def single_gpu_job(seed, steps, warmup, check_oracle=False, n=n, nb=nb, ext=None, make=None):
         """The N=1 step on this rank's own job.  -> (dt, comp_bytes, enc/dec kernel ms+launches, call ms, container == oracle's)"""
         ext = args.ext if ext is None else ext
-        host = make(n, seed) if make else tsq.synth.text(n, seed=seed)
+        host = make(n, seed) if make else make_input(n, seed)
         src = torch.from_numpy(host).to(dev)
         container = torch.empty(tsq.container_bound(n), dtype=torch.uint8, device=dev)
         back = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -353,7 +365,7 @@ def main():
             "value": round(aggregate_value(n, dt, args.steps), 4), "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"enwik9-shaped synthetic text, one {n} B job ({nb} blocks of 4 MiB), "
+            "config": {"workload": f"{kind_name}, one {n} B job ({nb} blocks of 4 MiB), "
                                    f"{'with-extensions' if args.ext else '--no-ext'} level, device-resident, bit-exact round trip",
                        "job_bytes": n, "blocks": nb, "ext": args.ext, "ratio": round(comp_bytes / n, 5),
                        "sharding": "1 GPU owns every block", "kernel_variant": args.variant,
@@ -448,7 +460,7 @@ def main():
     else:
         # ---- one job, blocks dealt round-robin over the ranks, container gathered in host memory
         lay = sharding.ShardLayout(n, rank, world)
-        host = tsq.synth.text(n, seed=1)                  # every rank generates the same job and keeps its blocks
+        host = make_input(n, 1)                           # every rank generates the same job and keeps its blocks
         d_shard = torch.from_numpy(lay.pack_input(host)).to(dev)
         expect = torch.from_numpy(lay.expected_output(host)).to(dev)
         del host
@@ -501,7 +513,7 @@ def main():
             if not args.no_oracle_check:
                 # ... and, outside the timed region, byte for byte the CPU oracle's container of the same job (the checker)
                 from oracle import pyoracle
-                want = pyoracle.Oracle().compress(tsq.synth.text(n, seed=1), args.ext, threads=min(32, os.cpu_count() or 1))
+                want = pyoracle.Oracle().compress(make_input(n, 1), args.ext, threads=min(32, os.cpu_count() or 1))
                 oracle_equal = bool(len(want) == comp_bytes and bytes(hc.array[:comp_bytes]) == want)
                 assert oracle_equal, "the host-gathered container differs from the oracle's"
         # the slowest rank's kernel times
@@ -523,7 +535,7 @@ def main():
                 "value": round(aggregate_value(n, dt, args.steps), 4), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                 "dtype": "u8", "data": "synthetic",
-                "config": {"workload": f"enwik9-shaped synthetic text, one {n} B job ({nb} blocks of 4 MiB) block-sharded over {world} GPUs, "
+                "config": {"workload": f"{kind_name}, one {n} B job ({nb} blocks of 4 MiB) block-sharded over {world} GPUs, "
                                        f"{'with-extensions' if args.ext else '--no-ext'} level, blocks resident in HBM, container gathered in host memory, bit-exact round trip",
                            "job_bytes": n, "blocks": nb, "ext": args.ext, "ratio": round(comp_bytes / n, 5),
                            "sharding": f"block b -> rank b % {world}; one all-gather of the u32 sizes per step, frames DMA'd to one host container, barrier, owned frames back and decoded",

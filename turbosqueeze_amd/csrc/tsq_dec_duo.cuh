@@ -609,6 +609,11 @@ __device__ __forceinline__ void duo_copy(const uint8_t* __restrict__ in, uint32_
 
 // NP PARSE workgroups and one COPY workgroup per block, all on one XCD: workgroup w -> (xcd = w % 8, slot = w / 8), role = slot % (NP + 1),
 // block = (slot / (NP + 1)) * 8 + xcd; the COPY workgroup (role NP) is dispatched last.
+#ifdef TSQ_STATS
+// instrumented builds: the XCD (XCC_ID) every workgroup of the last launch really ran on (tools/duo_xcd.py: how often do a block's
+// workgroups share one, as the index mapping below assumes?)
+__device__ uint32_t g_duo_xcc[2048];
+#endif
 template <uint32_t NP>
 __global__ __launch_bounds__(1024) void dec_duo_kernel(const uint8_t* __restrict__ container, const FrameInfo* __restrict__ frames, uint32_t n_blocks,
                                                        uint8_t* __restrict__ outbuf, int32_t* __restrict__ status,
@@ -617,6 +622,9 @@ __global__ __launch_bounds__(1024) void dec_duo_kernel(const uint8_t* __restrict
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t w = blockIdx.x, xcd = w & 7u, slot = w >> 3;
     const uint32_t role = slot % (NP + 1u), b = (slot / (NP + 1u)) * 8u + xcd;
+#ifdef TSQ_STATS
+    if (threadIdx.x == 0 && w < 2048u) { uint32_t id; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id)); g_duo_xcc[w] = 0x80000000u | (id & 15u); }
+#endif
     if (b >= n_blocks) return;
     // An error reported before this launch (the frame walk refused the container: the descriptors are not even written) or by
     // another block: leave, all threads together.  (A block's workgroups may read different values while another block is failing;

@@ -700,6 +700,10 @@ extern "C" int tsqa_debug_trace(uint32_t* out4096)
 {
     return hipMemcpyFromSymbol(out4096, HIP_SYMBOL(tsq::g_enc_trace), 4096 * sizeof(uint32_t)) == hipSuccess ? TSQA_OK : TSQA_ERR_HIP;
 }
+extern "C" int tsqa_debug_duo_xcc(uint32_t* out2048)
+{
+    return hipMemcpyFromSymbol(out2048, HIP_SYMBOL(tsq::g_duo_xcc), 2048 * sizeof(uint32_t)) == hipSuccess ? TSQA_OK : TSQA_ERR_HIP;
+}
 extern "C" int tsqa_debug_syms(uint32_t* out8192)
 {
     return hipMemcpyFromSymbol(out8192, HIP_SYMBOL(tsq::g_dbg_syms), 8192 * sizeof(uint32_t)) == hipSuccess ? TSQA_OK : TSQA_ERR_HIP;
