@@ -280,13 +280,20 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
             misc[0] = k;
             if (k >= C::MAXSN && x < slim) misc[4] = kErrStream;
         }
+#ifdef TSQ_X_DEC_FLUSH_P3
+        if (tid >= 64u) flush_image(64u, C::T - 64u);
+#endif
         __syncthreads();
         const uint32_t nsn = misc[0];
         TSQD_ACC(3);
 
         // ---------------- P4: one lane per group.  Group 16 k + r starts where r's bits lead from super node k.
         // (The upper half of the workgroup has no group to look after: it writes the PREVIOUS chunk's bytes to HBM meanwhile -- P7.)
+#ifdef TSQ_X_DEC_FLUSH_P3     // (experiment: the previous chunk's image goes out beside the single-lane chain of P3 instead of beside P4's groups)
+#elif defined(TSQ_X_DEC_NOFLUSH)   // (timing only, wrong output: what does the flush cost P4?)
+#else
         if (tid >= C::T / 2) flush_image(C::T / 2, C::T / 2);
+#endif
         {
             uint32_t x = C::TERM;
             if (tid < nsn * C::HOP) {

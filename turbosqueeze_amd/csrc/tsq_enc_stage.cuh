@@ -878,6 +878,8 @@ __device__ __forceinline__ uint32_t s_lt(uint32_t a, uint32_t b)
 { uint32_t d; asm("s_cmp_lt_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(d) : "s"(a), "s"(b) : "scc"); return d; }
 __device__ __forceinline__ uint32_t s_ge(uint32_t a, uint32_t b)
 { uint32_t d; asm("s_cmp_ge_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(d) : "s"(a), "s"(b) : "scc"); return d; }
+__device__ __forceinline__ uint32_t s_ne(uint32_t a, uint32_t b)
+{ uint32_t d; asm("s_cmp_lg_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(d) : "s"(a), "s"(b) : "scc"); return d; }
 __device__ __forceinline__ uint32_t s_eq(uint32_t a, uint32_t b)
 { uint32_t d; asm("s_cmp_eq_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(d) : "s"(a), "s"(b) : "scc"); return d; }
 __device__ __forceinline__ uint32_t s_offset_ok(uint32_t offset)          // tsq_encode.cpp:100
@@ -1277,7 +1279,13 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
             asm volatile("v_writelane_b32 %0, %1, 6" : "+v"(hv) : "s"(e_lit_from));
             asm volatile("v_writelane_b32 %0, %1, 7" : "+v"(hv) : "s"((uint32_t)Mt));
             asm volatile("v_writelane_b32 %0, %1, 8" : "+v"(hv) : "s"((uint32_t)(Mt >> 32)));
+            // (every lane stores: lanes 9 .. 15 put the kind word into the item's unused words, lanes above 15 into word 15 -- cheaper
+            //  than masking the wavefront down to nine lanes: no exec save / restore, no branch around an empty mask)
+#ifdef TSQ_X_HDRMASK
             if (lane < 9u) it[lane] = hv;
+#else
+            it[lane < 15u ? lane : 15u] = hv;
+#endif
             it[16 + lane] = lw;
             slot_publish();
         }
@@ -1342,30 +1350,88 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
     auto account_segment = [&](const uint64_t V) {
         // ---- the segment's effect on the symbol state, O(1) from its masks.  `dsym` symbols close (matches and
         //      the literal runs in front of them); the state afterwards hangs on the last match.
-        const uint64_t M = V & certain_m, N = V ^ M;
-        const uint32_t L0 = s_lsb64(V);
-        const uint32_t has_m = s_nz64(M);
-        const uint32_t Le = s_msb64(V | 1ull), Lm = s_msb64(M | 1ull);
-        const uint32_t first_isN = (uint32_t)(N >> L0) & 1u;                // L0 is the lowest lane of V
-        uint64_t r = N & (N >> 1); r &= r >> 2; r &= r >> 4; r &= r >> 8;     // a literal run of 16 or more inside
-        const uint32_t run_end = base + s_sel(has_m, s_lsb64(M | (1ull << 63)), Le + 1u);
-        const uint32_t chunk = s_ge(run_end - lit_from, 16u) & first_isN;     // the entry run completes a 16-byte chunk
-        if (__builtin_expect(s_nz64(r) | chunk, 0)) { TSQ_CNT(28, 1); replay_segment(V); }
+        // Two hand-written scalar blocks (ACCOUNT is one of the two wavefronts that pace the pipeline, and the compiler spends about
+        // twice the instructions on these flag computations: every 0/1 flag through a compare of its own, phi copies at every merge):
+        //   M = V & certain, N = V ^ M; L0 / Le lowest / highest visited lane, Lm highest match lane, fM lowest match lane;
+        //   first_isN: the segment enters on a literal; slow: a literal run of 16 or more inside, or the entry run completes a
+        //   16-byte chunk (then the segment is replayed step by step).
+        uint64_t M, N, T, R;
+        uint32_t L0, Le, Lm, fM, has_m, first_isN, slow, t1;
+        asm volatile(
+            "s_and_b64 %[M], %[V], %[C]\n\t"
+            "s_cselect_b32 %[hasm], 1, 0\n\t"
+            "s_xor_b64 %[N], %[V], %[M]\n\t"
+            "s_ff1_i32_b64 %[L0], %[V]\n\t"
+            "s_flbit_i32_b64 %[Le], %[V]\n\t"
+            "s_flbit_i32_b64 %[Lm], %[M]\n\t"
+            "s_ff1_i32_b64 %[fM], %[M]\n\t"
+            "s_xor_b32 %[Le], %[Le], 63\n\t"
+            "s_xor_b32 %[Lm], %[Lm], 63\n\t"
+            "s_bitcmp1_b64 %[N], %[L0]\n\t"
+            "s_cselect_b32 %[fN], 1, 0\n\t"
+            "s_lshr_b64 %[T], %[N], 1\n\t"
+            "s_and_b64 %[R], %[N], %[T]\n\t"
+            "s_lshr_b64 %[T], %[R], 2\n\t"
+            "s_and_b64 %[R], %[R], %[T]\n\t"
+            "s_lshr_b64 %[T], %[R], 4\n\t"
+            "s_and_b64 %[R], %[R], %[T]\n\t"
+            "s_lshr_b64 %[T], %[R], 8\n\t"
+            "s_and_b64 %[R], %[R], %[T]\n\t"
+            "s_cselect_b32 %[slow], 1, 0\n\t"
+            "s_add_i32 %[t1], %[Le], 1\n\t"
+            "s_cmp_lg_u32 %[hasm], 0\n\t"
+            "s_cselect_b32 %[t1], %[fM], %[t1]\n\t"
+            "s_add_i32 %[t1], %[t1], %[base]\n\t"
+            "s_sub_i32 %[t1], %[t1], %[lit]\n\t"
+            "s_cmp_ge_u32 %[t1], 16\n\t"
+            "s_cselect_b32 %[t1], %[fN], 0\n\t"
+            "s_or_b32 %[slow], %[slow], %[t1]"
+            : [M] "=&s"(M), [N] "=&s"(N), [T] "=&s"(T), [R] "=&s"(R), [L0] "=&s"(L0), [Le] "=&s"(Le), [Lm] "=&s"(Lm), [fM] "=&s"(fM),
+              [hasm] "=&s"(has_m), [fN] "=&s"(first_isN), [slow] "=&s"(slow), [t1] "=&s"(t1)
+            : [V] "s"(V), [C] "s"(certain_m), [base] "s"(base), [lit] "s"(lit_from)
+            : "scc");
+        if (__builtin_expect(slow, 0)) { TSQ_CNT(28, 1); replay_segment(V); }
         else {
-            const uint32_t e_pos = base + L0, lm_pos = base + Lm, endm = lm_pos + rdlane(span_nat, Lm);
-            const uint32_t last_m = s_eq(Le, Lm) & has_m;
-            const uint32_t pre = s_lt(lit_from, e_pos) & (first_isN ^ 1u);      // a pending literal closes in front of an entry match
-            const uint32_t dsym = (uint32_t)__builtin_popcountll(M) + (uint32_t)__builtin_popcountll(M & (N << 1)) + pre;
-            const uint32_t nsym_n = nsym + s_sel(has_m, dsym, 0u);
-            const uint32_t origin_n = s_sel(has_m, s_sel(nsym_n & 1u, lm_pos, endm), origin);
-            const uint32_t new_run = s_sel(has_m, last_m ^ 1u, am);              // a literal run starts inside / at the entry of the segment
-            run0 = s_sel(new_run, s_sel(has_m, endm, e_pos), run0);
-            origin_r0 = s_sel(new_run, origin_n, origin_r0);
-            odd_r0 = s_sel(new_run, nsym_n & 1u, odd_r0);
-            lit_from = s_sel(has_m, endm, lit_from);
-            am = last_m;
-            nsym = nsym_n;
-            origin = origin_n;
+            //   e_pos / lm_pos: where the segment enters / its last match starts, endm: where that match ends; last_m: the segment ends
+            //   with it; pre: a pending literal closes in front of an entry match; dsym: symbols closed (tsq_encode.cpp:93-95,113-115,157-159)
+            uint32_t sp, e_pos, lm_pos, endm, last_m, pre, d1, d2, par, t2, t3, new_run;
+            asm volatile(
+                "v_readlane_b32 %[sp], %[span], %[Lm]\n\t"
+                "s_add_i32 %[epos], %[base], %[L0]\n\t"
+                "s_add_i32 %[lmpos], %[base], %[Lm]\n\t"
+                "s_cmp_eq_u32 %[Le], %[Lm]\n\t"
+                "s_cselect_b32 %[lastm], %[hasm], 0\n\t"
+                "s_cmp_lt_u32 %[lit], %[epos]\n\t"
+                "s_cselect_b32 %[pre], 1, 0\n\t"
+                "s_andn2_b32 %[pre], %[pre], %[fN]\n\t"
+                "s_bcnt1_i32_b64 %[d1], %[M]\n\t"
+                "s_lshl_b64 %[T], %[N], 1\n\t"
+                "s_and_b64 %[T], %[T], %[M]\n\t"
+                "s_bcnt1_i32_b64 %[d2], %[T]\n\t"
+                "s_add_i32 %[d1], %[d1], %[d2]\n\t"
+                "s_add_i32 %[d1], %[d1], %[pre]\n\t"
+                "s_add_i32 %[endm], %[lmpos], %[sp]\n\t"
+                "s_xor_b32 %[t2], %[lastm], 1\n\t"
+                "s_cmp_lg_u32 %[hasm], 0\n\t"
+                "s_cselect_b32 %[d1], %[d1], 0\n\t"
+                "s_add_i32 %[nsym], %[nsym], %[d1]\n\t"
+                "s_and_b32 %[par], %[nsym], 1\n\t"
+                "s_cselect_b32 %[d2], %[lmpos], %[endm]\n\t"
+                "s_cmp_lg_u32 %[hasm], 0\n\t"
+                "s_cselect_b32 %[origin], %[d2], %[origin]\n\t"
+                "s_cselect_b32 %[newrun], %[t2], %[am]\n\t"
+                "s_cselect_b32 %[t3], %[endm], %[epos]\n\t"
+                "s_cselect_b32 %[lit], %[endm], %[lit]\n\t"
+                "s_cmp_lg_u32 %[newrun], 0\n\t"
+                "s_cselect_b32 %[run0], %[t3], %[run0]\n\t"
+                "s_cselect_b32 %[or0], %[origin], %[or0]\n\t"
+                "s_cselect_b32 %[odd0], %[par], %[odd0]\n\t"
+                "s_mov_b32 %[am], %[lastm]"
+                : [sp] "=&s"(sp), [epos] "=&s"(e_pos), [lmpos] "=&s"(lm_pos), [endm] "=&s"(endm), [lastm] "=&s"(last_m), [pre] "=&s"(pre),
+                  [d1] "=&s"(d1), [d2] "=&s"(d2), [par] "=&s"(par), [t2] "=&s"(t2), [t3] "=&s"(t3), [newrun] "=&s"(new_run), [T] "=&s"(T),
+                  [nsym] "+s"(nsym), [origin] "+s"(origin), [lit] "+s"(lit_from), [am] "+s"(am), [run0] "+s"(run0), [or0] "+s"(origin_r0), [odd0] "+s"(odd_r0)
+                : [span] "v"(span_nat), [M] "s"(M), [N] "s"(N), [L0] "s"(L0), [Le] "s"(Le), [Lm] "s"(Lm), [hasm] "s"(has_m), [fN] "s"(first_isN), [base] "s"(base)
+                : "scc");
         }
         Vt |= V; Mt |= M;
     };
@@ -1376,27 +1442,29 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
     uint32_t vw;
     // counters, next event, the tile's visited mask and class words in one breath; waits until there is an event or a walked tile
     auto snapshot = [&]() {
+        uint32_t w;
         for (;;) {
             volatile lds_u32_t* const e = evq + (ev_tail % StageCfg::EQ) * StageCfg::EV_WORDS;
             volatile lds_u32_t* const rec = recs + cur_slot * StageCfg::REC_WORDS;
             const u32x2_t hw = lds_ld2((volatile lds_u32_t*)ctl + kCtlEvHead);      // [4] events produced, [5] tiles walked
-            const uint32_t w = e[lane & 3u];
+            w = e[lane & 3u];
             vw = rec[2u + (lane & 1u)];
             ga = lds_ld2(rec + StageCfg::ARR + lane * 4u + kGA);
             asm volatile("" ::: "memory");
-            has_ev = uniform(hw.x) != ev_tail ? 1u : 0u;
+            has_ev = s_ne(uniform(hw.x), ev_tail);
             walked = uniform(hw.y);
-            kind = rdlane(w, 0); ea = rdlane(w, 1);
-            ev_is_cur = has_ev & (kind != kEvEnd ? 1u : 0u) & ((ea >> 6) == cur ? 1u : 0u);
-            if (__builtin_expect((has_ev | (walked != cur ? 1u : 0u)) != 0u, 1)) { eb = rdlane(w, 2); ec = rdlane(w, 3); return; }
+            // (flags as 0/1 integers from scalar compares: a C comparison that crosses a branch becomes a lane mask, a v_cndmask and a v_cmp)
+            if (has_ev | s_ne(walked, cur)) break;
 #ifdef TSQ_STATS
             const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
 #endif
             TSQ_SPIN(ctl); __builtin_amdgcn_s_sleep(1);
 #ifdef TSQ_STATS
-            st_[8] += __builtin_amdgcn_s_memtime() - w0_ + 60u;
+            st_[8] += __builtin_amdgcn_s_memtime() - w0_;
 #endif
         }
+        kind = rdlane(w, 0); ea = rdlane(w, 1); eb = rdlane(w, 2); ec = rdlane(w, 3);
+        ev_is_cur = has_ev & s_ne(kind, kEvEnd) & s_eq(ea >> 6, cur);
     };
     auto handle_event = [&]() {
         // ---- an event of the tile at hand
@@ -1479,7 +1547,162 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
             got |= bit;
         }
         };
+    auto finish_tile = [&]() {
+        cur++;
+        cur_slot = cur_slot + 1u == StageCfg::R ? 0u : cur_slot + 1u;
+        got = 0; opened = 0;
+        // (SCAN may reuse the records of the tiles before `cur`: everything ACCOUNT needs of them is in registers or in the queue)
+        __hip_atomic_store(&ctl[kCtlAccounted], cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // ---- The usual tile in one hand-written block (TSQ_ACCT_ASM): no event pending, the tile walked and not opened by an event, no
+    // literal run that reaches a 16-byte chunk boundary, room in the item queue.  It does what the loop body below does for such a tile
+    // -- requests the counters, the visited mask and the class words together, account_segment's two scalar blocks, the item's header
+    // and lane words, the queue head, the tile counter -- in about a hundred instructions and four not-taken branches; the compiled
+    // loop body spends about twice that (flags through lane masks, register copies where its paths merge, a branch pair per test).
+    // Whatever it does not handle leaves it untouched (code != 0) and goes through the compiled path below.  ACCOUNT and WALK are the two
+    // wavefronts that pace the pipeline.  s[60:83] and v[40:47] are its scratch registers.
+#if !defined(TSQ_NO_ACCT_ASM) && !defined(TSQ_STATS) && !defined(TSQ_SPINS) && !defined(TSQ_X_DELAY_STAGE)
+#define TSQ_ACCT_ASM 1
+    const uint32_t lds0 = (uint32_t)(size_t)lds;
+    const uint32_t a_ctl = lds0 + StageCfg::off_ctl;                                                   // ctl[0]
+    const uint32_t a_vis = lds0 + StageCfg::off_rec + 8u + (lane & 1u) * 4u;                           // record word 2 / 3
+    const uint32_t a_ga = lds0 + StageCfg::off_rec + StageCfg::ARR * 4u + lane * 16u;                  // group A of this lane
+    const uint32_t a_hdr = lds0 + StageCfg::off_queue + (lane < 15u ? lane : 15u) * 4u;                // item header word
+    const uint32_t a_lw = lds0 + StageCfg::off_queue + 64u + lane * 4u;                                // item lane word
+#endif
     for (;;) {
+#ifdef TSQ_ACCT_ASM
+        {
+            uint32_t code;
+            TSQ_JIT(head * 64u + 41u);
+            asm volatile(
+                "s_mul_i32 s61, %[slot], %[recb]\n\t"
+                "s_mov_b32 %[code], 1\n\t"
+                "v_add_u32_e32 v41, s61, %[avis]\n\t"
+                "v_add_u32_e32 v42, s61, %[aga]\n\t"
+                "v_mov_b32_e32 v40, %[actl]\n\t"
+                "ds_read_b64 v[44:45], v40 offset:16\n\t"          // ctl[4] events produced, ctl[5] tiles walked
+                "ds_read_b32 v43, v41\n\t"                         // visited mask: lane & 1 selects the word
+                "ds_read_b64 v[46:47], v42\n\t"                    // spanword, lane word
+                "s_sub_u32 s64, %[head], %[tseen]\n\t"
+                "s_lshl_b32 s82, %[cur], 6\n\t"                    // base
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_readfirstlane_b32 s62, v44\n\t"
+                "v_readfirstlane_b32 s63, v45\n\t"
+                "s_cmp_lg_u32 s62, %[evt]\n\t"
+                "s_cbranch_scc1 9f\n\t"                            // an event is pending
+                "s_cmp_eq_u32 s63, %[cur]\n\t"
+                "s_cbranch_scc1 9f\n\t"                            // the tile is not walked yet
+                "s_cmp_ge_u32 s64, %[Q]\n\t"
+                "s_cbranch_scc1 9f\n\t"                            // the item queue looks full
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_readlane_b32 s64, v43, 0\n\t"
+                "v_readlane_b32 s65, v43, 1\n\t"                   // V = s[64:65]
+                "v_bfe_u32 v41, v46, 10, 1\n\t"
+                "v_and_b32_e32 v40, 0xff, v46\n\t"                 // natural span
+                "v_cmp_ne_u32_e64 s[66:67], 0, v41\n\t"            // certain match lanes
+                "s_cmp_eq_u64 s[64:65], 0\n\t"
+                "s_cbranch_scc1 9f\n\t"
+                // ---- account_segment, first block: M s[68:69], N s[70:71], T s[72:73], R s[74:75], L0 s76, Le s77, Lm s78, fM s79, has_m s80, first_isN s81
+                "s_and_b64 s[68:69], s[64:65], s[66:67]\n\t"
+                "s_cselect_b32 s80, 1, 0\n\t"
+                "s_xor_b64 s[70:71], s[64:65], s[68:69]\n\t"
+                "s_ff1_i32_b64 s76, s[64:65]\n\t"
+                "s_flbit_i32_b64 s77, s[64:65]\n\t"
+                "s_flbit_i32_b64 s78, s[68:69]\n\t"
+                "s_ff1_i32_b64 s79, s[68:69]\n\t"
+                "s_xor_b32 s77, s77, 63\n\t"
+                "s_xor_b32 s78, s78, 63\n\t"
+                "s_bitcmp1_b64 s[70:71], s76\n\t"
+                "s_cselect_b32 s81, 1, 0\n\t"
+                "s_lshr_b64 s[72:73], s[70:71], 1\n\t"
+                "s_and_b64 s[74:75], s[70:71], s[72:73]\n\t"
+                "s_lshr_b64 s[72:73], s[74:75], 2\n\t"
+                "s_and_b64 s[74:75], s[74:75], s[72:73]\n\t"
+                "s_lshr_b64 s[72:73], s[74:75], 4\n\t"
+                "s_and_b64 s[74:75], s[74:75], s[72:73]\n\t"
+                "s_lshr_b64 s[72:73], s[74:75], 8\n\t"
+                "s_and_b64 s[74:75], s[74:75], s[72:73]\n\t"
+                "s_cbranch_scc1 9f\n\t"                            // a literal run of 16 or more inside
+                "s_add_i32 s60, s77, 1\n\t"
+                "s_cmp_lg_u32 s80, 0\n\t"
+                "s_cselect_b32 s60, s79, s60\n\t"
+                "s_add_i32 s60, s60, s82\n\t"
+                "s_sub_i32 s60, s60, %[lit]\n\t"
+                "s_cmp_ge_u32 s60, 16\n\t"
+                "s_cselect_b32 s60, s81, 0\n\t"
+                "s_cmp_lg_u32 s60, 0\n\t"
+                "s_cbranch_scc1 9f\n\t"                            // the entry run completes a 16-byte chunk
+                // ---- the item's header, from the state as it stands at the tile's entry
+                "v_mov_b32_e32 v41, 1\n\t"                         // kItemSeg
+                "v_readlane_b32 s61, v40, s78\n\t"                 // span of the last match lane
+                "v_writelane_b32 v41, s82, 1\n\t"
+                "s_add_i32 s62, s82, s76\n\t"                      // e_pos
+                "v_writelane_b32 v41, s64, 2\n\t"
+                "s_add_i32 s63, s82, s78\n\t"                      // lm_pos
+                "v_writelane_b32 v41, s65, 3\n\t"
+                "s_cmp_eq_u32 s77, s78\n\t"
+                "v_writelane_b32 v41, %[nsym], 4\n\t"
+                "s_cselect_b32 s83, s80, 0\n\t"                    // last_m
+                "v_writelane_b32 v41, %[origin], 5\n\t"
+                "s_cmp_lt_u32 %[lit], s62\n\t"
+                "v_writelane_b32 v41, %[lit], 6\n\t"
+                "s_cselect_b32 s60, 1, 0\n\t"
+                "v_writelane_b32 v41, s68, 7\n\t"
+                "s_andn2_b32 s60, s60, s81\n\t"                    // pre
+                "v_writelane_b32 v41, s69, 8\n\t"
+                // ---- account_segment, second block
+                "s_bcnt1_i32_b64 s66, s[68:69]\n\t"
+                "s_lshl_b64 s[72:73], s[70:71], 1\n\t"
+                "s_and_b64 s[72:73], s[72:73], s[68:69]\n\t"
+                "s_bcnt1_i32_b64 s67, s[72:73]\n\t"
+                "s_add_i32 s66, s66, s67\n\t"
+                "s_add_i32 s66, s66, s60\n\t"                      // dsym
+                "s_add_i32 s61, s63, s61\n\t"                      // endm
+                "s_xor_b32 s67, s83, 1\n\t"
+                "s_cmp_lg_u32 s80, 0\n\t"
+                "s_cselect_b32 s66, s66, 0\n\t"
+                "s_add_i32 %[nsym], %[nsym], s66\n\t"
+                "s_and_b32 s66, %[nsym], 1\n\t"                    // parity; SCC = odd
+                "s_cselect_b32 s60, s63, s61\n\t"
+                "s_cmp_lg_u32 s80, 0\n\t"
+                "s_cselect_b32 %[origin], s60, %[origin]\n\t"
+                "s_cselect_b32 s67, s67, %[am]\n\t"                // new_run
+                "s_cselect_b32 s60, s61, s62\n\t"
+                "s_cselect_b32 %[lit], s61, %[lit]\n\t"
+                "s_cmp_lg_u32 s67, 0\n\t"
+                "s_cselect_b32 %[run0], s60, %[run0]\n\t"
+                "s_cselect_b32 %[or0], %[origin], %[or0]\n\t"
+                "s_cselect_b32 %[odd0], s66, %[odd0]\n\t"
+                "s_mov_b32 %[am], s83\n\t"
+                // ---- the item: header word per lane, lane words, then the queue head; the tile counter
+                "s_and_b32 s60, %[head], %[Qm]\n\t"
+                "s_mulk_i32 s60, %[itemb]\n\t"
+                "v_add_u32_e32 v42, s60, %[ahdr]\n\t"
+                "v_add_u32_e32 v43, s60, %[alw]\n\t"
+                "s_add_i32 %[head], %[head], 1\n\t"
+                "ds_write_b32 v42, v41\n\t"
+                "ds_write_b32 v43, v47\n\t"
+                "v_mov_b32_e32 v40, %[actl]\n\t"
+                "v_mov_b32_e32 v42, %[head]\n\t"
+                "s_add_i32 %[cur], %[cur], 1\n\t"
+                "s_add_i32 %[slot], %[slot], 1\n\t"
+                "ds_write_b32 v40, v42\n\t"                        // ctl[0]: items published
+                "v_mov_b32_e32 v43, %[cur]\n\t"
+                "s_cmp_lg_u32 %[slot], %[R]\n\t"
+                "s_cselect_b32 %[slot], %[slot], 0\n\t"
+                "ds_write_b32 v40, v43 offset:56\n\t"              // ctl[14]: tiles accounted
+                "s_mov_b32 %[code], 0\n"
+                "9:"
+                : [code] "=&s"(code), [nsym] "+s"(nsym), [origin] "+s"(origin), [lit] "+s"(lit_from), [am] "+s"(am), [run0] "+s"(run0),
+                  [or0] "+s"(origin_r0), [odd0] "+s"(odd_r0), [head] "+s"(head), [cur] "+s"(cur), [slot] "+s"(cur_slot)
+                : [evt] "s"(ev_tail), [tseen] "s"(tail_seen + opened * 0x40000000u), [actl] "s"(a_ctl), [avis] "v"(a_vis), [aga] "v"(a_ga), [ahdr] "v"(a_hdr), [alw] "v"(a_lw),
+                  [recb] "n"(StageCfg::REC_WORDS * 4u), [Q] "n"(StageCfg::Q), [Qm] "n"(StageCfg::Q - 1u), [itemb] "n"(StageCfg::ITEM_WORDS * 4u), [R] "n"(StageCfg::R)
+                : "scc", "memory", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76",
+                  "s77", "s78", "s79", "s80", "s81", "s82", "s83", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
+            if (code == 0u) { e_nsym = nsym; e_origin = origin; e_lit_from = lit_from; continue; }
+        }
+#endif
         snapshot();
         // (a tile's events -- queries and the lanes visited in front of them -- are rare; the usual tile goes straight through below)
         while (__builtin_expect(ev_is_cur != 0u, 0)) { handle_event(); snapshot(); }
@@ -1491,11 +1714,7 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
         open_tile(ga);
         if (V != 0ull) account_segment(V);
         flush_pending();                              // the tile's item goes to the builder
-        cur++;
-        cur_slot = cur_slot + 1u == StageCfg::R ? 0u : cur_slot + 1u;
-        got = 0; opened = 0;
-        // (SCAN may reuse the records of the tiles before `cur`: everything ACCOUNT needs of them is in registers or in the queue)
-        __hip_atomic_store(&ctl[kCtlAccounted], cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        finish_tile();
     }
     flush_pending();
 #ifdef TSQ_STATS
