@@ -34,6 +34,7 @@ PY
 ) > $OUT/traffic_experiment_pmc.log 2>&1
 timeout 300 python tools/quick_check.py > $OUT/quick_check.txt 2>&1
 for n in 1073741824 4294967296; do timeout 300 python tools/config5_sweep.py $n 1 2>/dev/null; done > $OUT/config5.jsonl
+timeout 900 python tools/config5_full.py > $OUT/config5_full_10gib.jsonl 2>/dev/null
 # more blocks than CUs with a partial last round: 1.25 GiB + 4 KiB of text = 321 blocks (256 + 65), and one GPU's share of config 5 at N = 8:
 # 320 blocks of the 50 % mix with extensions (256 + 64)
 timeout 300 python tools/config5_sweep.py 1342181376 0 0 text 2>/dev/null >> $OUT/config5.jsonl
@@ -47,4 +48,6 @@ mkdir -p gpurun_out/x; bash tools/bottleneck.sh run > $OUT/bottleneck.txt 2>&1
 python tools/spin_counts.py > $OUT/spin_counts.txt 2>&1
 bash tools/sq_counters.sh $TAG > gpurun_out/${TAG}_sq.log 2>&1
 bash tools/sq_units.sh > $OUT/sq_units.txt 2>&1
+timeout 200 python tools/duo_xcd.py 2>&1 | grep -v amdgpu.ids > $OUT/duo_xcd.txt
+tools/micro/hostcopy > $OUT/hostcopy.txt 2>&1
 ls -la $OUT

@@ -23,4 +23,8 @@ cp $S/spin_counts.txt profiles/${TAG}_encoder_spin_counts.txt
 [ -f gpurun_out/${TAG}_sq.log ] && grep -v amdgpu.ids gpurun_out/${TAG}_sq.log > profiles/${TAG}_sq_counters.txt
 [ -f $S/regions.txt ] && cp $S/regions.txt profiles/${TAG}_walk_regions.txt
 [ -f $S/sq_units.txt ] && grep -v amdgpu.ids $S/sq_units.txt > profiles/${TAG}_sq_units.txt
+[ -f $S/kernel_by_shape.json ] && cp $S/kernel_by_shape.json profiles/${TAG}_kernel_by_shape.json
+[ -f $S/config5_full_10gib.jsonl ] && cp $S/config5_full_10gib.jsonl profiles/${TAG}_config5_full_10gib.jsonl
+[ -f $S/duo_xcd.txt ] && cp $S/duo_xcd.txt profiles/${TAG}_duo_xcd.txt
+[ -f $S/hostcopy.txt ] && cp $S/hostcopy.txt profiles/${TAG}_hostcopy.txt
 ls -la profiles/${TAG}_*

@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 for pair in "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT"; do
   name=$(echo $pair | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $pair -d $OUT/$name -o c --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/$name.log 2>&1
+  rocprofv3 --kernel-trace --pmc $pair -d $OUT/$name -o c --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/$name.log 2>&1
 done
 python - <<PY
 import csv, glob, collections

@@ -5,7 +5,7 @@ OUT=gpurun_out/sq_units; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 for pair in "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" "SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT" "SQ_INSTS_LDS SQ_LDS_UNALIGNED_STALL" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_MISC"; do
   name=$(echo $pair | tr ' ' '_')
-  timeout 120 rocprofv3 --kernel-trace --pmc $pair -d $OUT/$name -o c --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/$name.log 2>&1
+  timeout 120 rocprofv3 --kernel-trace --pmc $pair -d $OUT/$name -o c --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/$name.log 2>&1
 done
 python - <<PY
 import csv, glob, collections
