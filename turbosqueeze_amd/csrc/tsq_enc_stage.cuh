@@ -551,7 +551,9 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         MREG_BEGIN(12);
         // ---- the table holds the visits of tiles <= t-LM-1 (the COMMIT wave has published them: its stores are complete and the
         //      wavefronts of a workgroup share the vector L1): gather from it right away, without waiting for the parser ...
+#ifndef TSQ_X_NOCOMMITWAIT     // (timing only, wrong streams: the gather does not wait for COMMIT -- what does the loop WALK -> COMMIT -> MATCH -> ORBIT -> WALK cost?)
         if (t >= LM + 1u && !stage_wait_seen(ctl, kCtlCommitted, t - LM, committed_seen, 3)) break;
+#endif
         TSQ_TRACE(10, t);
 #ifdef TSQ_X_EXTRA_GATHER   // perturbation (streams unchanged): a second, equally cold gather per lane -- what the table's line traffic costs shows as the slowdown
         const uint32_t tv_extra = table[h ^ 0x1AAAAu];
@@ -567,7 +569,11 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         // visited twin there (SCAN's exact mask) takes the most recent one -- what the committed table would hold --, the others
         // keep theirs.
         uint32_t tv = tv_old;
+#ifdef TSQ_X_NOPATCH      // timing only (streams differ where a twin in tile t-LM was visited): MATCH does not wait for WALK's verdict on tile t-LM
+        if (false) {
+#else
         if (t >= LM) {
+#endif
             volatile lds_u32_t* vis = recs + ((t - LM) % StageCfg::R) * StageCfg::REC_WORDS + 2u;
             uint32_t vis_lo, vis_hi;
             {   // (counter and visited mask requested together: one LDS round trip less on the lag loop)
