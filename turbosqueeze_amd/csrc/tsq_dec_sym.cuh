@@ -73,7 +73,16 @@ struct SymLds {
     static constexpr uint32_t misc = wsum + 64;                                     // u32[16]
     static constexpr uint32_t lut = misc + 64;                                      // u16[1024]: (two control bits, size byte) -> stream bytes of the pair
     static constexpr uint32_t ring = (lut + 2048 + 15) & ~15u;                      // u8[R + RPAD]
-    static constexpr uint32_t total = ring + SymCfg::R + SymCfg::RPAD;
+    // The pipelined decoder (dec_sym_kernel built with -DTSQ_DEC_PIPE; an experiment, off: bit-exact, and 4 - 6 % SLOWER -- 4.73 ms with the
+    // parse beside the pointer jumping, 4.80 beside the record scan, against 4.55: every wavefront runs the same sequence, so the next
+    // chunk's parse and this chunk's copy phases do not overlap inside a wavefront, and across wavefronts they are in the same phase at
+    // the same time): the NEXT chunk's stream is staged, and every offset of it parsed as a group start, while the
+    // current chunk's bytes are being resolved -- `stage` lies behind the symbol records in the part of the doubling tables that is dead
+    // during the copy phases, `j1x` (next - offset of the chunk after) behind the ring, where nothing overwrites it until its chunk is parsed.
+    static constexpr uint32_t stage = recw + 4 * (SymCfg::OUTC + 16);                // u8[S + SPAD + 16]: the next chunk's stream (P5 of this one)
+    static constexpr uint32_t j1x = ring + SymCfg::R + SymCfg::RPAD;                 // u8[S]
+    static constexpr uint32_t total = j1x + SymCfg::S;
+    static_assert(stage % 16 == 0 && stage + 16 * SymCfg::SWORDS <= gstart, "the staged stream fits behind the records");
     static_assert(SymCfg::R % 16 == 0, "ring phase");
     static_assert(recw % 16 == 0 && recw + 4 * (SymCfg::OUTC + 16) <= gstart && plist % 16 == 0 && plist + 2 * SymCfg::OUTC <= gstart,
                   "records, byte entries and waiting lists fit the dead doubling tables");
@@ -107,7 +116,12 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
     using C = SymCfg;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t* const s_raw = lds + SymLds::sbuf;
+#ifndef TSQ_DEC_PIPE
     uint8_t* const j1 = lds + SymLds::j1;
+#else
+    uint8_t* const j1 = lds + SymLds::j1x;
+    uint16_t* const lut = reinterpret_cast<uint16_t*>(lds + SymLds::lut);
+#endif
     uint16_t* const j2 = reinterpret_cast<uint16_t*>(lds + SymLds::j2);
     uint16_t* const j4 = reinterpret_cast<uint16_t*>(lds + SymLds::j4);
     uint16_t* const j8 = reinterpret_cast<uint16_t*>(lds + SymLds::j8);
@@ -184,13 +198,57 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
         if (tid < C::SWORDS && (tid << 4) + 16u <= lim) __builtin_memcpy(&pre, in + at + (tid << 4), 16);
     };
     prefetch(sp);
+#ifdef TSQ_DEC_PIPE
+    // The chunk's stream into LDS at `dst` (sbuf[k] = in[at + k]; zeros beyond the stream): the words prefetched into registers, the
+    // stream's last, partial word byte by byte (once per block).
+    auto stage_chunk = [&](uint8_t* dst, uint32_t at) {
+        if (tid < C::SWORDS) {
+            uint4 w = pre;
+            const uint32_t av = in_len - at;
+            const uint32_t lim = av < C::S + C::SPAD ? av : C::S + C::SPAD, o = tid << 4;
+            if (o < lim && o + 16u > lim) {
+                uint32_t b[4] = {0, 0, 0, 0};
+                for (uint32_t k = 0; o + k < lim; ++k) b[k >> 2] |= (uint32_t)in[at + o + k] << (8u * (k & 3u));
+                w = make_uint4(b[0], b[1], b[2], b[3]);
+            }
+            *reinterpret_cast<uint4*>(dst + (tid << 4)) = w;
+        }
+    };
+    // P1 on the stream at `src`: every byte offset parsed AS IF a group started there -- the control byte, then per pair the size byte and
+    // the pair's stream length from the 2 KB table (two control bits, size byte) -- ; next - offset goes to j1.  (This form needs no
+    // scratch table over the doubling tables, which hold the current chunk's records while it runs.)
+    auto parse_every_offset = [&](const uint8_t* src) {
+        uint32_t x[C::PER], y[C::PER], c[C::PER];
+#pragma unroll
+        for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t o = tid + k * C::T; c[k] = src[o]; x[k] = o + 1u; }
+#pragma unroll
+        for (uint32_t pr = 0; pr < 4; ++pr) {
+#pragma unroll
+            for (uint32_t k = 0; k < C::PER; ++k) y[k] = src[x[k]];                        // x < S + 133: inside the padded buffer
+#pragma unroll
+            for (uint32_t k = 0; k < C::PER; ++k) y[k] = lut[(((c[k] >> (6u - 2u * pr)) & 3u) << 8) | y[k]];
+#pragma unroll
+            for (uint32_t k = 0; k < C::PER; ++k) x[k] += y[k];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t o = tid + k * C::T; j1[o] = (uint8_t)(x[k] - o); }
+    };
+    { uint32_t sl, ol; pair_lens(tid & 255u, tid >> 8, 0u, sl, ol); lut[tid] = (uint16_t)sl; }
     __syncthreads();
+    // the first chunk: staged and parsed here; every later one while the chunk before it is being copied (below)
+    stage_chunk(s_raw, sp);
+    __syncthreads();
+    parse_every_offset(s_raw);
+#else
+    __syncthreads();
+#endif
 
     while (op < size) {
-        // ---------------- P0: the chunk (loaded a chunk ago) goes to LDS.  sbuf[k] = in[sp + k]; zeros beyond the stream.
         const uint32_t avail = in_len - sp;
         const uint32_t slim = avail < C::S ? avail : C::S;
         uint8_t* const sbuf = s_raw;
+#ifndef TSQ_DEC_PIPE
+        // ---------------- P0: the chunk (loaded a chunk ago) goes to LDS.  sbuf[k] = in[sp + k]; zeros beyond the stream.
         if (tid < C::SWORDS) {
             uint4 w = pre;
             const uint32_t lim = avail < C::S + C::SPAD ? avail : C::S + C::SPAD, o = tid << 4;
@@ -201,7 +259,10 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
             }
             *reinterpret_cast<uint4*>(s_raw + (tid << 4)) = w;
         }
+#endif
         if (tid == 0) { misc[0] = 0; misc[1] = 0; misc[2] = 0xFFFFFFFFu; misc[3] = 0xFFFFFFFFu; misc[5] = 0; }
+        // (pipelined: the chunk's stream is in sbuf and j1 holds its parse at every offset -- both made during the previous chunk's copy
+        //  phases; this barrier also ends the previous chunk's ring write, which reads the byte entries the doubling tables now overwrite)
         __syncthreads();
         TSQD_ACC(0); TSQD_CNT(12, 1);
 
@@ -210,7 +271,9 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
         // group further on, again consecutive) collide in the LDS banks.  A lane keeps its own entries in registers from pass to
         // pass.  An offset at or beyond slim is terminal (TERM).
         {
-            uint32_t x[C::PER], y[C::PER], c[C::PER];
+            uint32_t x[C::PER], y[C::PER];
+#ifndef TSQ_DEC_PIPE
+            uint32_t c[C::PER];
             // (A) every byte of the chunk taken as a size byte: the stream length of the pair it would head, for each of the four
             //     control-bit pairs, packed in one word: 5 | 4 + lo << 8 | 4 + hi << 16 | 3 + hi + lo << 24 (tsq_decode.cpp:66-88: a
             //     literal takes nibble + 1 bytes, a match two).  One lane per aligned word of the chunk, arithmetic only.  The table
@@ -251,6 +314,10 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
 #pragma unroll
             for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t o = tid + k * C::T; j1[o] = (uint8_t)(x[k] - o); x[k] = o < slim ? x[k] : C::TERM; }
             __syncthreads();
+#else
+#pragma unroll
+            for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t o = tid + k * C::T; x[k] = o < slim ? o + j1[o] : C::TERM; }
+#endif
             TSQD_ACC(1);
 #pragma unroll
             for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t a = x[k] < slim ? x[k] : 0u; y[k] = a + j1[a]; }
@@ -415,9 +482,18 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
             }
         }
         if (bad) misc[4] = kErrStream;
+#ifdef TSQ_DEC_PIPE
+        // ---- the next chunk (its stream was requested behind P4): staged behind the records now, parsed at every offset beside the
+        //      record scan below (vector work: the parse is LDS look-ups), copied to its place beside the ring write -- P0 and P1 of
+        //      chunk k+1 inside the copy phases of chunk k
+        if (!last_chunk) stage_chunk(lds + SymLds::stage, next_sp);
+#endif
         __syncthreads();
         if (misc[4] != 0) { if (tid == 0) atomicMax(status, (int32_t)misc[4]); return; }
         TSQD_ACC(5);
+#ifdef TSQ_DEC_PIPE
+        if (!last_chunk) parse_every_offset(lds + SymLds::stage);
+#endif
         // (b) one lane per 12 bytes: every byte takes the record of the symbol it lies in (the last record at or before it)
         typedef __attribute__((address_space(3))) uint16_t lds_u16;
         lds_u16* const le = (lds_u16*)(lds + SymLds::ent);                             // byte entries: 0x8000 | value when final, else source index
@@ -544,7 +620,11 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
                 *reinterpret_cast<uint32_t*>(ring + x) = (lo & 0xFFu) | ((lo >> 8) & 0xFF00u) | ((hi & 0xFFu) << 16) | ((hi >> 16) << 24);
             }
         }
-        // (no barrier here: nothing reads the ring, and nothing overwrites the entries, before the next chunk's P0 barrier)
+#ifdef TSQ_DEC_PIPE
+        if (!last_chunk && tid < C::SWORDS)
+            *reinterpret_cast<uint4*>(s_raw + (tid << 4)) = *reinterpret_cast<const uint4*>(lds + SymLds::stage + (tid << 4));
+#endif
+        // (no barrier here: nothing reads the ring, and nothing overwrites the entries, before the barrier at the top of the next chunk)
         TSQD_ACC(7);
 #ifdef TSQ_STATS
         if (tid == 0) { st_[14] += misc[9]; st_[11] += misc[10]; misc[9] = 0; misc[10] = 0; }
