@@ -268,7 +268,7 @@ def main():
                     help="the job's synthetic input: enwik9-shaped text (the headline), or one of BASELINE config 5's inputs")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the extra sections (the other level, config 5's inputs, the host-gather step)")
     ap.add_argument("--config5-size", type=int, default=1 << 30)
-    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = production, 1 = serial baselines, 5 = round 2's encoder from the A/B library)")
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 = production, 1 = serial baselines, 5 = the previous round's production encoder, frozen in the A/B library)")
     args = ap.parse_args()
 
     import numpy as np
