@@ -77,3 +77,51 @@ def test_reference_programs_link_against_this_library(tmp_path, source):
     exported = subprocess.run(["nm", "-D", "--defined-only", tsq.lib_path()], capture_output=True, text=True).stdout
     have = {l.split()[-1] for l in exported.splitlines()}
     assert wanted <= have, sorted(wanted - have)
+
+
+def test_pmc_summary_keys_by_kernel_and_launch_shape(tmp_path):
+    """tools/pmc_summary.py (the source of bench.py's roofline.traffic): a kernel launched at two grid sizes in one profiled command
+    gets one entry per launch shape ("<kernel>@<blocks>") beside the all-launch entry, and bench.py picks the timed job's shape."""
+    import csv
+    import importlib.util
+    import json
+    import sys
+    d = tmp_path / "fetch" / "x"
+    d.mkdir(parents=True)
+    rows = [("tsq::dec_sym_kernel(unsigned char const*)", 239 * 1024, 1024, 100.0), ("tsq::dec_sym_kernel(unsigned char const*)", 1024 * 1024, 1024, 400.0),
+            ("tsq::dec_sym_kernel(unsigned char const*)", 1024 * 1024, 1024, 420.0), ("void at::native::fill(int)", 256, 256, 5.0)]
+    for sub in ("fetch", "write"):
+        dd = tmp_path / sub / "x"
+        dd.mkdir(parents=True, exist_ok=True)
+        with open(dd / "p_counter_collection.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Grid_Size", "Workgroup_Size", "Kernel_Name", "Counter_Name", "Counter_Value"])
+            for name, grid, wg, val in rows:
+                w.writerow([grid, wg, name, sub.upper() + "_SIZE", val])
+    spec = importlib.util.spec_from_file_location("pmc_summary", os.path.join(ROOT, "tools", "pmc_summary.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = tmp_path / "s.json"
+    mod.pmc(str(out), [f"fetch={tmp_path / 'fetch'}", f"write={tmp_path / 'write'}"])
+    s = json.load(open(out))
+    assert s["fetch"]["tsq::dec_sym_kernel@239"]["per_dispatch"] == 100.0
+    assert s["fetch"]["tsq::dec_sym_kernel@1024"]["per_dispatch"] == 410.0 and s["fetch"]["tsq::dec_sym_kernel@1024"]["dispatches"] == 2
+    assert s["fetch"]["tsq::dec_sym_kernel"]["dispatches"] == 3 and not any("fill" in k for k in s["fetch"])
+    # bench.py takes the entry of the timed job's own launch shape, and only from a summary made from the running kernel sources
+    sys.path.insert(0, ROOT)
+    import bench
+    import turbosqueeze_amd as tsq
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    json.dump(s, open(prof / "r99_pmc_fetch_write.json", "w"))
+    old_root = bench.ROOT
+    try:
+        bench.ROOT = str(tmp_path)
+        got, src = bench.pmc_traffic("dec_", 239, tsq.source_fingerprint())
+        assert got == int((2 * 100.0 + 100.0) * 1024) and "@239" in src
+        got, why = bench.pmc_traffic("dec_", 500, tsq.source_fingerprint())
+        assert got is None and "500 blocks" in why
+        got, why = bench.pmc_traffic("dec_", 239, "another-fingerprint")
+        assert got is None and "other kernel sources" in why
+    finally:
+        bench.ROOT = old_root

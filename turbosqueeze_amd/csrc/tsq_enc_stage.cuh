@@ -1033,7 +1033,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
             asm volatile(
                 "s_add_i32 s61, %[t], 1\n\t"
                 "s_lshl_b32 s62, %[t], 6\n\t"                      // base
-                "s_waitcnt lgkmcnt(0)\n\t"                         // the record requested at the end of the previous tile
+                "s_waitcnt lgkmcnt(4)\n\t"                         // ORBIT's counter, requested at the end of the previous tile in front of the record
                 "v_readfirstlane_b32 s60, v62\n\t"
                 "s_mul_i32 s81, %[slot], %[recb]\n\t"
                 "s_cmp_lt_u32 s60, s61\n\t"
@@ -1061,25 +1061,28 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                 "2:\n\t"
                 // ---- the tile's prologue: lanes with a twin visited in the previous tiles, near-twin lanes, certain matches
                 "s_sub_i32 s66, %[v], s62\n\t"                     // entry lane
-                "v_lshrrev_b32_e32 v47, 24, v48\n\t"               // where the orbit from each lane halts
-                "v_bfe_u32 v41, v48, 12, 1\n\t"
                 "s_mov_b64 s[68:69], %[p1]\n\t"
                 "s_mov_b64 s[70:71], %[p2]\n\t"
                 "s_mov_b64 s[72:73], %[p3]\n\t"
-                "v_add_u32_e32 v41, -1, v41\n\t"                   // all ones unless ORBIT settled the lane's twins in t-3
-                "v_and_b32_e32 %[ph], s68, v56\n\t"                // twins in t-1 that were visited
-                "v_and_b32_e32 v45, s69, v57\n\t"
-                "v_and_b32_e32 v42, v60, v41\n\t"
-                "v_and_b32_e32 v43, v61, v41\n\t"
-                "v_and_or_b32 %[ph], v58, s70, %[ph]\n\t"          // ... in t-2
-                "v_and_or_b32 v45, v59, s71, v45\n\t"
-                "v_and_or_b32 %[ph], v42, s72, %[ph]\n\t"          // ... in t-3
-                "v_and_or_b32 v45, v43, s73, v45\n\t"
+                "s_waitcnt lgkmcnt(3)\n\t"                         // group A has arrived (the groups come back in the order they were asked for)
+                "v_lshrrev_b32_e32 v47, 24, v48\n\t"               // where the orbit from each lane halts
+                "v_bfe_u32 v41, v48, 12, 1\n\t"
                 "v_bfe_u32 v46, v48, 11, 1\n\t"
                 "v_bfe_u32 v44, v48, 10, 1\n\t"
-                "v_or_b32_e32 %[ph], %[ph], v45\n\t"
+                "v_add_u32_e32 v41, -1, v41\n\t"                   // all ones unless ORBIT settled the lane's twins in t-3
                 "v_cmp_ne_u32_e64 %[nearm], 0, v46\n\t"
                 "v_cmp_ne_u32_e64 %[certm], 0, v44\n\t"
+                "s_waitcnt lgkmcnt(1)\n\t"                         // groups B, C
+                "v_and_b32_e32 %[ph], s68, v56\n\t"                // twins in t-1 that were visited
+                "v_and_b32_e32 v45, s69, v57\n\t"
+                "v_and_or_b32 %[ph], v58, s70, %[ph]\n\t"          // ... in t-2
+                "v_and_or_b32 v45, v59, s71, v45\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"                         // group D
+                "v_and_b32_e32 v42, v60, v41\n\t"
+                "v_and_b32_e32 v43, v61, v41\n\t"
+                "v_and_or_b32 %[ph], v42, s72, %[ph]\n\t"          // ... in t-3
+                "v_and_or_b32 v45, v43, s73, v45\n\t"
+                "v_or_b32_e32 %[ph], %[ph], v45\n\t"
                 "s_mov_b64 %[Vo], 0\n"
                 // ---- one segment: the orbit from lane s66, up to its first lane whose gathered candidate is stale
                 "4:\n\t"
