@@ -29,6 +29,8 @@ for s in ${SANITIZERS:-tsan asan}; do
     ( env $env TSQ_AMD_DEVICES=0,0 timeout ${SAN_TIMEOUT:-300} $R/tsq_cli_$s c $W/in.bin $W/out$k.tsq; env $env TSQ_AMD_DEVICES=0,0 timeout ${SAN_TIMEOUT:-300} $R/tsq_cli_$s d $W/out$k.tsq $W/back$k.bin; cmp $W/in.bin $W/back$k.bin && echo "round trip ok" ) > $OUT/${s}_cli_files_$k.log 2>&1; echo "exit $?" >> $OUT/${s}_cli_files_$k.log
   done
   ( TSQ_AMD_DEVICES=0,0 timeout ${SAN_TIMEOUT:-300} $R/tsq_cli_$s b --synthetic 100000000 --reps 2 ) > $OUT/${s}_cli_bench.log 2>&1; echo "exit $?" >> $OUT/${s}_cli_bench.log
+  # one device, 72 blocks, results above 64 MiB: the ramped batches, the striped first touch of the result and its wait-for-my-pages
+  ( timeout ${SAN_TIMEOUT:-300} $R/tsq_cli_$s b --synthetic 300000000 --reps 1 ) > $OUT/${s}_cli_bench_ramped.log 2>&1; echo "exit $?" >> $OUT/${s}_cli_bench_ramped.log
 done
 rm -rf $W
 {
