@@ -1896,7 +1896,7 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
                 "s_and_b64 s[74:75], s[74:75], s[72:73]\n\t"
                 "s_lshr_b64 s[72:73], s[74:75], 8\n\t"
                 "s_and_b64 s[74:75], s[74:75], s[72:73]\n\t"
-                "s_cbranch_scc1 9f\n\t"                            // a literal run of 16 or more inside
+                "s_cbranch_scc1 6f\n\t"                            // a literal run of 16 or more inside: below
                 "s_add_i32 s60, s77, 1\n\t"
                 "s_cmp_lg_u32 s80, 0\n\t"
                 "s_cselect_b32 s60, s79, s60\n\t"
@@ -1948,7 +1948,50 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
                 "s_cselect_b32 %[or0], %[origin], %[or0]\n\t"
                 "s_cselect_b32 %[odd0], s66, %[odd0]\n\t"
                 "s_mov_b32 %[am], s83\n\t"
+                "s_branch 7f\n"
+                // ---- a literal run of 16 or more.  Taken here when the whole segment is ONE run of literals and nothing else (incompressible
+                //      data: every lane visited, no match); any other shape goes to the compiled path, which replays the segment run by run.
+                "6:\n\t"
+                "s_cmp_lg_u32 s80, 0\n\t"
+                "s_cbranch_scc1 9f\n\t"
+                "s_lshr_b64 s[72:73], s[64:65], s76\n\t"
+                "s_add_u32 s60, s72, 1\n\t"
+                "s_addc_u32 s61, s73, 0\n\t"
+                "s_and_b64 s[60:61], s[60:61], s[72:73]\n\t"       // zero when the visited lanes are consecutive
+                "s_cbranch_scc1 9f\n\t"
+                "v_mov_b32_e32 v41, 1\n\t"                         // kItemSeg
+                "s_bcnt1_i32_b64 s62, s[64:65]\n\t"                // the run's length
+                "v_writelane_b32 v41, s82, 1\n\t"
+                "s_add_i32 s63, s82, s76\n\t"                      // where it starts
+                "v_writelane_b32 v41, s64, 2\n\t"
+                "s_and_b32 s60, %[nsym], 1\n\t"
+                "v_writelane_b32 v41, s65, 3\n\t"
+                "s_cmp_lg_u32 %[am], 0\n\t"                        // right behind a match: a new literal run starts here
+                "v_writelane_b32 v41, %[nsym], 4\n\t"
+                "s_cselect_b32 %[run0], s63, %[run0]\n\t"
+                "v_writelane_b32 v41, %[origin], 5\n\t"
+                "s_cselect_b32 %[or0], %[origin], %[or0]\n\t"
+                "v_writelane_b32 v41, %[lit], 6\n\t"
+                "s_cselect_b32 %[odd0], s60, %[odd0]\n\t"
+                "v_writelane_b32 v41, s68, 7\n\t"
+                "s_mov_b32 %[am], 0\n\t"
+                "v_writelane_b32 v41, s69, 8\n\t"
+                "s_add_i32 s60, s63, s62\n\t"
+                "s_sub_i32 s60, s60, %[lit]\n\t"
+                "s_lshr_b32 s60, s60, 4\n\t"                       // 16-byte chunks that complete inside the run (tsq_encode.cpp:82-97)
+                "s_add_i32 %[nsym], %[nsym], s60\n\t"
+                "s_lshl_b32 s61, s60, 4\n\t"
+                "s_add_i32 s61, s61, %[lit]\n\t"                   // the pending literal starts here afterwards
+                "s_add_i32 s62, s61, -16\n\t"
+                "s_cmp_ge_u32 s60, 2\n\t"
+                "s_cselect_b32 s62, s62, %[origin]\n\t"            // odd count: the chunk before the last closed a pair (if there are two)
+                "s_bitcmp0_b32 %[nsym], 0\n\t"
+                "s_cselect_b32 s62, s61, s62\n\t"                  // even count: the last chunk closed a pair
+                "s_cmp_lg_u32 s60, 0\n\t"
+                "s_cselect_b32 %[origin], s62, %[origin]\n\t"
+                "s_mov_b32 %[lit], s61\n"
                 // ---- the item: header word per lane, lane words, then the queue head; the tile counter
+                "7:\n\t"
                 "s_and_b32 s60, %[head], %[Qm]\n\t"
                 "s_mulk_i32 s60, %[itemb]\n\t"
                 "v_add_u32_e32 v42, s60, %[ahdr]\n\t"
