@@ -14,7 +14,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     codec = tsq.DeviceCodec(0)
     out = {}
     for n in [int(float(x)) for x in sys.argv[3:]]:
-        src = torch.from_numpy(tsq.synth.text(n, 1)).cuda()
+        kind = os.environ.get("QC_KIND", "text")
+        import numpy as np
+        host = {"text": lambda: tsq.synth.text(n, 1), "zeros": lambda: np.zeros(n, dtype=np.uint8), "random": lambda: tsq.synth.random_bytes(n, 3), "mix": lambda: tsq.synth.mix(n, 3)}[kind]()
+        src = torch.from_numpy(host).cuda()
         dst = torch.empty(api.container_bound(n), dtype=torch.uint8, device="cuda")
         ext = int(os.environ.get("QC_EXT", "0"))
         codec.compress_async(src, ext, dst); torch.cuda.synchronize()
