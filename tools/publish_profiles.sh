@@ -28,3 +28,6 @@ cp $S/spin_counts.txt profiles/${TAG}_encoder_spin_counts.txt
 [ -f $S/duo_xcd.txt ] && cp $S/duo_xcd.txt profiles/${TAG}_duo_xcd.txt
 [ -f $S/hostcopy.txt ] && cp $S/hostcopy.txt profiles/${TAG}_hostcopy.txt
 ls -la profiles/${TAG}_*
+[ -f $S/tile_trace.txt ] && grep -v amdgpu.ids $S/tile_trace.txt > profiles/${TAG}_tile_trace.txt
+[ -f $S/sq_icache.txt ] && grep -v amdgpu.ids $S/sq_icache.txt > profiles/${TAG}_sq_icache.txt
+true

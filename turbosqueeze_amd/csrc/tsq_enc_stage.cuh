@@ -160,8 +160,13 @@ enum : uint32_t { kCtlEvHead = 4, kCtlOrbitEven = 10, kCtlEvTail = 11, kCtlRepli
 #else
 #define MREG_BEGIN(k) do {} while (0)
 #define MREG_END(k) do {} while (0)
+#ifdef TSQ_MARKS      // (-S builds: the parser's regions show in the assembly)
+#define REG_BEGIN(k) asm volatile("; REG_BEGIN " #k ::: "memory")
+#define REG_END(k) asm volatile("; REG_END " #k ::: "memory")
+#else
 #define REG_BEGIN(k) do {} while (0)
 #define REG_END(k) do {} while (0)
+#endif
 #define TSQ_BEGIN() do {} while (0)
 #endif
 
@@ -708,6 +713,7 @@ __device__ __forceinline__ void stage_commit(uint32_t n, uint16_t* table, lds_u8
         // (requesting the tile's hashes and in-tile twins in front of this wait and polling without sleeping -- COMMIT is a member of the
         //  lag loop WALK -> COMMIT -> MATCH -> ORBIT -> WALK -- was measured: 39.4 ms against 39.3, nothing)
         if (!stage_wait(ctl, 5, t + 1u, 3)) break;
+        TSQ_TRACE(12, t);
         const u32x4_t gb = lds_ld4(arr + kGB);
         const uint32_t h = gb.y, tin_lo = gb.z, tin_hi = gb.w;
         const uint64_t tw = __ballot((tin_lo | tin_hi) != 0u);                             // lanes with an earlier twin inside the tile
@@ -1026,6 +1032,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
         static_assert(true, "");
 #endif
         {
+            TSQ_TRACE_ALL(8, t);                          // (with the hand-written tile: in front of its wait for ORBIT)
             TSQ_JIT((t + 1u) * 64u + 5u);
             TSQ_DELAY(6);
             // (the compiler carries these two round the loop in vector registers -- it takes them for lane-dependent behind the hazard loop's exits)
@@ -1209,7 +1216,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
 #ifdef TSQ_X_WALK_COUNT
             cnt_[code]++;
 #endif
-            if (code == 0u) continue;
+            if (code == 0u) { TSQ_TRACE_ALL(9, t); continue; }
             // the compiled body goes on with the tile: the record from the fixed registers
             asm volatile(
                 "v_mov_b32_e32 %0, v48\n\tv_mov_b32_e32 %1, v49\n\tv_mov_b32_e32 %2, v50\n\tv_mov_b32_e32 %3, v51\n\t"
@@ -1249,7 +1256,9 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
             }
 #endif
             TSQ_CNT(15, 1);
+#ifndef TSQ_WALK_ASM
             TSQ_TRACE(8, t);
+#endif
             const uint32_t settled = (spanword & 0x1000u) ? 0u : 0xFFFFFFFFu;     // ORBIT has settled the lane's twins in tiles t-LF .. t-LM+1
             const uint32_t tp2_lo = LF <= 2u ? tp2r_lo & settled : tp2r_lo, tp2_hi = LF <= 2u ? tp2r_hi & settled : tp2r_hi;
             const uint32_t tp3_lo = tp3r_lo & settled, tp3_hi = tp3r_hi & settled;
@@ -1825,6 +1834,7 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
         got = 0; opened = 0;
         // (SCAN may reuse the records of the tiles before `cur`: everything ACCOUNT needs of them is in registers or in the queue)
         __hip_atomic_store(&ctl[kCtlAccounted], cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        TSQ_TRACE_ALL(13, cur - 1u);
     };
     // ---- The usual tile in one hand-written block (TSQ_ACCT_ASM): no event pending, the tile walked and not opened by an event, no
     // literal run that reaches a 16-byte chunk boundary, room in the item queue.  It does what the loop body below does for such a tile
@@ -2016,7 +2026,7 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
                   [recb] "n"(StageCfg::REC_WORDS * 4u), [Q] "n"(StageCfg::Q), [Qm] "n"(StageCfg::Q - 1u), [itemb] "n"(StageCfg::ITEM_WORDS * 4u), [R] "n"(StageCfg::R)
                 : "scc", "memory", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76",
                   "s77", "s78", "s79", "s80", "s81", "s82", "s83", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
-            if (code == 0u) { e_nsym = nsym; e_origin = origin; e_lit_from = lit_from; continue; }
+            if (code == 0u) { e_nsym = nsym; e_origin = origin; e_lit_from = lit_from; TSQ_TRACE_ALL(13, cur - 1u); continue; }
         }
 #endif
         snapshot();

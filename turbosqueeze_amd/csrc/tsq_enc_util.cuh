@@ -7,12 +7,17 @@
 namespace tsq {
 
 // Instrumented builds (-DTSQ_STATS, make stats): block 0 publishes cycle and event counters.
-#ifdef TSQ_STATS
-__device__ unsigned long long g_enc_stats[64];
-// ... and a timeline: when each stage handed over each of 256 tiles (block 0, tiles kTraceFrom ..), low 32 bits of s_memtime
+// (-DTSQ_TRACEONLY: the timeline alone, at production timing -- tools/tile_trace.py)
+#if defined(TSQ_STATS) || defined(TSQ_TRACEONLY)
+// a timeline: when each stage handed over each of 256 tiles (block 0, tiles kTraceFrom ..), low 32 bits of s_memtime
 __device__ uint32_t g_enc_trace[16 * 256];
 constexpr uint32_t kTraceFrom = 20000;
-#define TSQ_TRACE(stage, t) do { if (blockIdx.x == 0 && (threadIdx.x & 63u) == 0 && (t) >= kTraceFrom && (t) < kTraceFrom + 256u) g_enc_trace[(stage) * 256 + ((t) - kTraceFrom)] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
+#define TSQ_TRACE(stage, t) do { if (blockIdx.x == 0 && (t) - kTraceFrom < 256u) { if ((threadIdx.x & 63u) == 0) g_enc_trace[(stage) * 256 + ((t) - kTraceFrom)] = (uint32_t)__builtin_amdgcn_s_memtime(); } } while (0)
+// (the same stored by every lane: for the scalar stages, where a one-lane branch makes the compiler move uniform values to vector registers)
+#define TSQ_TRACE_ALL(stage, t) do { if (blockIdx.x == 0 && (t) - kTraceFrom < 256u) g_enc_trace[(stage) * 256 + ((t) - kTraceFrom)] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
+#endif
+#ifdef TSQ_STATS
+__device__ unsigned long long g_enc_stats[64];
 #define TSQ_T0() unsigned long long t0_ = __builtin_amdgcn_s_memtime()
 #define TSQ_ACC(slot) do { unsigned long long t1_ = __builtin_amdgcn_s_memtime(); st_[slot] += t1_ - t0_; t0_ = t1_; } while (0)
 #define TSQ_CNT(slot, v) st_[slot] += (v)
@@ -24,7 +29,10 @@ constexpr uint32_t kTraceFrom = 20000;
 #define TSQ_ACC(slot) do {} while (0)
 #endif
 #define TSQ_T0() do {} while (0)
+#ifndef TSQ_TRACEONLY
 #define TSQ_TRACE(stage, t) do {} while (0)
+#define TSQ_TRACE_ALL(stage, t) do {} while (0)
+#endif
 #define TSQ_CNT(slot, v) do {} while (0)
 #define TSQ_SUB(slot) TSQ_ACC(slot)
 #endif

@@ -688,6 +688,12 @@ extern "C" int tsqa_debug_spins(uint32_t* out16)
     return hipMemcpyFromSymbol(out16, HIP_SYMBOL(tsq::g_enc_spins), 20 * sizeof(uint32_t)) == hipSuccess ? TSQA_OK : TSQA_ERR_HIP;
 }
 #endif
+#if defined(TSQ_STATS) || defined(TSQ_TRACEONLY)
+extern "C" int tsqa_debug_trace(uint32_t* out4096)
+{
+    return hipMemcpyFromSymbol(out4096, HIP_SYMBOL(tsq::g_enc_trace), 4096 * sizeof(uint32_t)) == hipSuccess ? TSQA_OK : TSQA_ERR_HIP;
+}
+#endif
 #ifdef TSQ_STATS
 // instrumented builds only: counters published by block 0 of the last encode / decode launch
 extern "C" int tsqa_debug_stats(unsigned long long* enc64, unsigned long long* dec16)
@@ -695,10 +701,6 @@ extern "C" int tsqa_debug_stats(unsigned long long* enc64, unsigned long long* d
     if (enc64 && hipMemcpyFromSymbol(enc64, HIP_SYMBOL(tsq::g_enc_stats), 64 * sizeof(unsigned long long)) != hipSuccess) return TSQA_ERR_HIP;
     if (dec16 && hipMemcpyFromSymbol(dec16, HIP_SYMBOL(tsq::g_dec_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return TSQA_ERR_HIP;
     return TSQA_OK;
-}
-extern "C" int tsqa_debug_trace(uint32_t* out4096)
-{
-    return hipMemcpyFromSymbol(out4096, HIP_SYMBOL(tsq::g_enc_trace), 4096 * sizeof(uint32_t)) == hipSuccess ? TSQA_OK : TSQA_ERR_HIP;
 }
 extern "C" int tsqa_debug_duo_xcc(uint32_t* out2048)
 {
