@@ -370,9 +370,12 @@ def test_encoder_handoffs_under_jitter(tsq, oracle):
         host = np.tile(one, 96)
         dev = to_dev(host)
         for ext in (0, 1):
-            blob = to_bytes(c.compress(dev, ext))
             want = oracle.compress(host, ext, threads=8)
-            assert blob == want, (seed, ext)
+            # the standard layout (MATCH and ORBIT on two pairs of wavefronts without extensions, fused into four with them) and the
+            # lean one (variant 6: fused at both levels)
+            for variant in (0, 6):
+                c.set_variant(variant, 0)
+                assert to_bytes(c.compress(dev, ext)) == want, (seed, ext, variant)
     c.close()
 
 

@@ -18,14 +18,17 @@ L.tsqa_debug_trace.argtypes = [C.c_void_p]
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 ext = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 codec = tsq.DeviceCodec(0)
-src = torch.from_numpy(tsq.synth.text(10 ** 9, 1)).cuda()
+kind = os.environ.get("TSQ_TRACE_KIND", "text")          # text | zeros | random | mix
+n_in = 10 ** 9 if kind == "text" else 1 << 30
+src = torch.from_numpy({"text": lambda: tsq.synth.text(n_in, 1), "zeros": lambda: np.zeros(n_in, dtype=np.uint8), "random": lambda: tsq.synth.random_bytes(n_in, 3),
+                        "mix": lambda: tsq.synth.mix(n_in, 3)}[kind]()).cuda()
 out = torch.empty(api.container_bound(src.numel()), dtype=torch.uint8, device="cuda")
 codec.compress(src, ext, out)
 codec.profile(True)
 codec.compress_async(src, ext, out)
 torch.cuda.synchronize()
 em, en, _, _ = codec.profile_read(); codec.profile(False)
-print("%s: encode kernel %.2f ms" % (LIB, em / max(en, 1)))
+print("%s, %s input, ext=%d: encode kernel %.2f ms" % (LIB, kind, ext, em / max(en, 1)))
 tr = np.zeros(4096, dtype=np.uint32)
 assert L.tsqa_debug_trace(tr.ctypes.data) == 0
 tr = tr.reshape(16, 256).astype(np.int64)

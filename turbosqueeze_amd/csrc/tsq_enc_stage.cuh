@@ -140,7 +140,7 @@ __device__ __forceinline__ void lds_st2(volatile lds_u32_t* p, uint32_t a, uint3
 // events between WALK and ACCOUNT, and their ctl words (4 events produced, 11 consumed, 12 queries answered, 13 the answer,
 // 14 the tile ACCOUNT works on: the tiles before it are accounted)
 enum : uint32_t { kEvSeg = 1, kEvHaz = 2, kEvEnd = 3 };
-enum : uint32_t { kCtlEvHead = 4, kCtlOrbitEven = 10, kCtlEvTail = 11, kCtlReplies = 12, kCtlReplyValue = 13, kCtlAccounted = 14, kCtlOrbitOdd = 15, kCtlCommitted = 33, kCtlHashed = 34, kCtlMatchedOdd = 35, kCtlNear = 36, kCtlIn = 37 };
+enum : uint32_t { kCtlEvHead = 4, kCtlOrbitEven = 10, kCtlEvTail = 11, kCtlReplies = 12, kCtlReplyValue = 13, kCtlAccounted = 14, kCtlOrbitOdd = 15, kCtlCommitted = 33, kCtlHashed = 34, kCtlMatchedOdd = 35, kCtlNear = 36, kCtlIn = 37, kCtlOrbitQ = 16 /* .. 19: tiles with orbits by t % 4 (stage_match_orbit) */ };
 
 // Instrumented builds time only the spin loops (and only when they actually spin): s_memtime costs a few
 // hundred cycles, so finer timing distorts the pipeline it measures.  busy = total - waited.
@@ -870,6 +870,217 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
 #endif
 }
 
+// ------------------------------------------------------------------------------------- MATCH + ORBIT on one wavefront per tile
+// Four wavefronts take the tiles t % 4 == which and do both stages' work for them (the same statements as stage_match and stage_orbit:
+// what is said there is not repeated): no record store, counter, poll and reload between the two, and four tile periods per wavefront
+// instead of two.  Measured against the two pairs above (encode kernel, ms, 239 / 256 blocks and the lean layout's 1 024): text without
+// extensions 39.3 against 39.0 and 115.1 against 118.3; text with extensions 41.8 / 42.3 and 121.8 / 125.4; zeros with extensions
+// **40.3 / 52.9 and 115.0 / 143.3** (every lane's match goes through the three extension rounds: two MATCH wavefronts are the bottleneck
+// there); the 50 % mix 42.6 / 43.4 and 135.2 / 139.0; random bytes 41.3 / 41.6 and 168.7 / 167.6.  FusedMO picks it for every kernel but
+// the one the headline runs (no extensions, window in LDS), where the pairs are 0.7 % faster.  The late classification runs behind
+// MATCH's here (in front of the gather's use it costs text 0.5 ms).  (The two forms share no helper functions on purpose: the same
+// statements moved into inlined helpers came out 0.45 ms slower for the pairs and 2.5 ms slower in the lean layout -- scheduling.)
+#if defined(TSQ_FUSED_OFF) || defined(TSQ_WALK_ASM_ON)
+template <bool EXT, bool WINDOW> struct FusedMO { static constexpr bool value = false; };
+#elif defined(TSQ_FUSED_ALL)
+template <bool EXT, bool WINDOW> struct FusedMO { static constexpr bool value = true; };
+#else
+template <bool EXT, bool WINDOW> struct FusedMO { static constexpr bool value = EXT || !WINDOW; };
+#endif
+// ORBIT's counter of tile t: one ctl word per even / odd tile, or one per t % 4
+template <bool EXT, bool WINDOW>
+__device__ __forceinline__ uint32_t orbit_word(uint32_t t)
+{ return FusedMO<EXT, WINDOW>::value ? kCtlOrbitQ + (t & 3u) : ((t & 1u) ? kCtlOrbitOdd : kCtlOrbitEven); }
+template <bool EXT, bool WINDOW>
+__device__ __forceinline__ uint32_t orbit_word_after(uint32_t t)          // of tile t + 1
+{ return FusedMO<EXT, WINDOW>::value ? kCtlOrbitQ + ((t + 1u) & 3u) : ((t & 1u) ? kCtlOrbitEven : kCtlOrbitOdd); }
+
+template <bool EXT, bool WINDOW>
+__device__ __forceinline__ void stage_match_orbit(const uint8_t* src, uint64_t avail, uint32_t n, uint16_t* table, lds_u8_t* lds, uint32_t lane, uint32_t which)
+{
+    using StageCfg = StageCfgT<WINDOW>;
+    volatile lds_u32_t* recs = (volatile lds_u32_t*)(lds + StageCfg::off_rec);
+    lds_u32_t* ctl = (lds_u32_t*)(lds + StageCfg::off_ctl);
+    constexpr uint32_t kDMin = EXT ? 128u : 64u;
+    constexpr uint32_t LM = StageCfg::LM, LF = StageCfg::LF;
+    const uint32_t tail_from = n >= 5u ? n - 5u : 0u;
+    const uint32_t n_tiles = (n >> 6) + 3u;
+    uint32_t wbase = which << 6;                       // (t * 64) % WIN
+    uint32_t scanned_seen = 0, committed_seen = 0, parsed_seen = 0, near_seen = 0;
+#ifdef TSQ_STATS
+    unsigned long long st_[32] = {0};
+#endif
+    TSQ_BEGIN();
+    for (uint32_t t = which; t < n_tiles; t += 4u) {
+        if (!stage_wait_seen(ctl, 2, t + 1u, scanned_seen, 2)) break;
+        TSQ_TRACE(3, t);
+        volatile lds_u32_t* rec = recs + (t % StageCfg::R) * StageCfg::REC_WORDS;
+        volatile lds_u32_t* arr = rec + StageCfg::ARR + lane * 4u;
+        const u32x4_t gb = lds_ld4(arr + kGB);
+        const u32x4_t wv = *(volatile lds_u32x4_t*)(rec + StageCfg::W16 + lane * 4u);
+        const u32x4_t gc = lds_ld4(arr + kGC);
+        const u32x4_t gd = lds_ld4(arr + kGD);
+        const uint32_t h = gb.y;
+        const uint4 w16 = make_uint4(wv.x, wv.y, wv.z, wv.w);
+        const uint64_t twin_in = (uint64_t)gb.z | ((uint64_t)gb.w << 32);
+        const uint64_t twin_p1 = (uint64_t)gc.x | ((uint64_t)gc.y << 32);
+        const uint32_t tpw_any = LM == 4u ? (gc.z | gc.w | gd.x | gd.y) : (gc.z | gc.w);
+        const uint32_t tpm_lo = LM == 4u ? gd.z : gd.x, tpm_hi = LM == 4u ? gd.w : gd.y;
+        // ---- MATCH: the gather behind COMMIT(t - LM - 1), the patch behind WALK(t - LM) (see stage_match)
+        if (t >= LM + 1u && !stage_wait_seen(ctl, kCtlCommitted, t - LM, committed_seen, 3)) break;
+        TSQ_TRACE(10, t);
+        const uint32_t tv_old = table[h];
+        uint32_t tv = tv_old;
+        if (t >= LM) {
+            volatile lds_u32_t* vis = recs + ((t - LM) % StageCfg::R) * StageCfg::REC_WORDS + 2u;
+            uint32_t vis_lo, vis_hi;
+            {
+                const uint32_t seen_v = ((volatile lds_u32_t*)ctl)[5];
+                uint32_t a = vis[0], b = vis[1];
+                asm volatile("" ::: "memory");
+                if (uniform(seen_v) < t - LM + 1u) {
+                    if (!stage_wait_tight(ctl, 5, t - LM + 1u, 3)) break;
+                    a = vis[0]; b = vis[1];
+                }
+                vis_lo = uniform(a); vis_hi = uniform(b);
+            }
+            TSQ_TRACE(4, t);
+            const uint32_t hit_lo = tpm_lo & vis_lo, hit_hi = tpm_hi & vis_hi;
+            const uint32_t q = hit_hi ? 63u - (uint32_t)__builtin_clz(hit_hi) : 31u - (uint32_t)__builtin_clz(hit_lo | 1u);
+            if ((hit_lo | hit_hi) != 0u) tv = (((t - LM) << 6) + q) & 0xFFFFu;
+        }
+        // ---- ORBIT: the late classification of the lanes whose only twins are in tiles t-LF .. t-LM+1 (see stage_orbit), from the
+        //      masks this wavefront already holds
+        uint32_t fix_sw = 0, fix_lw = 0;
+        bool fix = false, clear_far = false;
+        const uint32_t p = (t << 6) + lane;
+        auto late_fix = [&]() -> bool {
+        if (TSQ_LATE_FIX && t >= LF) {
+            const uint32_t tp_lo[4] = {0u, gc.x, gc.z, gd.x}, tp_hi[4] = {0u, gc.y, gc.w, gd.y};
+            uint32_t nearer = gb.z | gb.w, far = 0;
+#pragma unroll
+            for (uint32_t k = 1; k < LM; ++k) { if (k < LF) nearer |= tp_lo[k] | tp_hi[k]; else far |= tp_lo[k] | tp_hi[k]; }
+            const bool only_far = far != 0u && nearer == 0u && p < tail_from;
+            if (__ballot(only_far) != 0ull) {
+                if (!stage_wait_seen(ctl, 5, t - LF + 1u, parsed_seen, 5)) return false;
+                uint32_t hit_lo = 0, hit_hi = 0, back = 0;
+#pragma unroll
+                for (uint32_t k = LM - 1u; k >= LF; --k) {
+                    lds_u32_t* vis = (lds_u32_t*)(recs + ((t - k) % StageCfg::R) * StageCfg::REC_WORDS + 2u);
+                    const uint32_t v_lo = uniform(__hip_atomic_load(&vis[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    const uint32_t v_hi = uniform(__hip_atomic_load(&vis[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    const uint32_t h_lo = tp_lo[k] & v_lo, h_hi = tp_hi[k] & v_hi;
+                    if ((h_lo | h_hi) != 0u) { hit_lo = h_lo; hit_hi = h_hi; back = k; }
+                }
+                clear_far = only_far;
+                if (only_far && (hit_lo | hit_hi) != 0u) {
+                    const uint32_t q = hit_hi ? 63u - (uint32_t)__builtin_clz(hit_hi) : 31u - (uint32_t)__builtin_clz(hit_lo);
+                    const uint32_t cand = (t << 6) - (back << 6) + q;
+                    const uint32_t tq = t - back;
+                    const u32x4_t b = *(volatile lds_u32x4_t*)(recs + (tq % StageCfg::R) * StageCfg::REC_WORDS + StageCfg::W16 + q * 4u);
+                    const uint32_t k = prefix16(w16, make_uint4(b.x, b.y, b.z, b.w));
+                    if (p - cand >= kDMin && !(EXT && k >= 16u)) {
+                        const bool eq4f = k >= 4u;
+                        const uint32_t nibf = length_nibble(eq4f ? k : 4u);
+                        fix_sw = (eq4f ? nibble_span(nibf) | 0x400u : 1u) | (k << 16);
+                        fix_lw = cand | (nibf << 24);
+                        fix = true;
+                    } else clear_far = false;
+                }
+            }
+        }
+        return true;
+        };
+        const uint32_t cand0 = candidate_of(tv, p);
+        uint4 cb;
+        if (WINDOW) {
+            int32_t wi = (int32_t)(wbase + lane) - (int32_t)(p - cand0);
+            wi += wi < 0 ? (int32_t)StageCfg::WIN : 0;
+            volatile lds_u32_t* wp = (volatile lds_u32_t*)(lds + StageCfg::off_win + ((uint32_t)wi & ~3u));
+            const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2], d3 = wp[3], d4 = wp[4];
+            const uint32_t sh = (uint32_t)wi & 3u;
+            cb = make_uint4(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                            __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh));
+            if (cand0 + 19u > ((t + 1u) << 6) || p - cand0 > 65536u) cb = ld128z(src, cand0, avail);
+        }
+        else cb = ld128z(src, cand0, avail);
+        uint32_t k0 = prefix16(w16, cb);
+        if (EXT) {
+            uint32_t more = 16;
+            if (__ballot(k0 == more) != 0ull) {
+                const uint32_t scanned = uniform(__hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                const bool in_window = WINDOW && scanned >= t + 2u;
+                auto win16 = [&](int32_t wi) -> uint4 {
+                    wi += wi < 0 ? (int32_t)StageCfg::WIN : 0;
+                    wi -= wi >= (int32_t)StageCfg::WIN ? (int32_t)StageCfg::WIN : 0;
+                    volatile lds_u32_t* wp = (volatile lds_u32_t*)(lds + StageCfg::off_win + ((uint32_t)wi & ~3u));
+                    const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2], d3 = wp[3], d4 = wp[4];
+                    const uint32_t sh = (uint32_t)wi & 3u;
+                    return make_uint4(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                                      __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh));
+                };
+                while (__ballot(k0 == more) != 0ull && more < 64u) {
+                    if (k0 == more) {
+                        if (in_window && p - cand0 <= 65536u)
+                            k0 += prefix16(win16((int32_t)(wbase + lane + more)), win16((int32_t)(wbase + lane + more) - (int32_t)(p - cand0)));
+                        else
+                            k0 += prefix16(ld128z(src, (uint64_t)p + more, avail), ld128z(src, (uint64_t)cand0 + more, avail));
+                    }
+                    more += 16;
+                }
+            }
+        }
+        const uint32_t dist = p - cand0;
+        const bool eq4 = k0 >= 4u;
+        const bool far_enough = dist >= kDMin && dist <= 0xFFFEu;
+        const bool tail = p >= tail_from;
+        bool neart = false;
+        if (__ballot((twin_in | twin_p1) != 0ull) != 0ull) {
+            const uint64_t near_in = twin_in & ~below(lane >= 3u ? lane - 3u : 0u);
+            const uint64_t near_prev = lane < 3u ? twin_p1 & ~below(61u + lane) : 0ull;
+            neart = (near_in | near_prev) != 0ull && !tail;
+        }
+        const bool certain = eq4 && far_enough && !tail && !neart;
+        const uint32_t nib = length_nibble(k0 < 4u ? 4u : k0);
+        const uint32_t span_nat = certain ? nibble_span(nib) : 1u;
+        const bool hard_m = (eq4 && !far_enough && dist >= 4u && !neart) || tail;
+        const bool twin_l = (twin_in | twin_p1) != 0ull || tpw_any != 0u;
+        uint32_t sw = span_nat | (hard_m ? 0x100u : 0u) | (twin_l ? 0x200u : 0u) | (certain ? 0x400u : 0u) | (neart ? 0x800u : 0u) | (k0 << 16);
+        uint32_t lw = cand0 | (nib << 24);
+        TSQ_TRACE(5, t);
+        TSQ_TRACE(11, t);
+        if (!late_fix()) break;
+        if (fix) { sw = fix_sw; lw = fix_lw; }
+        if (clear_far) sw |= 0x1000u;
+        // ---- the whole orbit of every lane, by pointer doubling (see stage_orbit)
+        const uint32_t self = lane | ((sw & 0x100u) ? 0x80u : 0u);
+        const uint32_t c = lane + (sw & 0xFFu);
+        const uint32_t there = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((c & 63u) << 2), (int)self);
+        uint32_t nx = c >= 64u ? (c | 0x80u) : there;
+        uint64_t orb = 1ull << lane;
+#pragma unroll
+        for (int round = 0; round < 6; ++round) {
+            const int at = (int)((nx & 63u) << 2);
+            const uint32_t nx2 = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)nx);
+            const uint32_t olo = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)(uint32_t)orb);
+            const uint32_t ohi = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)(uint32_t)(orb >> 32));
+            if ((nx & 0x80u) == 0u) { nx = nx2; orb |= (uint64_t)olo | ((uint64_t)ohi << 32); }
+        }
+        if (!stage_wait_seen(ctl, kCtlNear, t + 1u, near_seen, 6)) break;
+        const bool hard_l = (sw & 0x100u) != 0u;
+        const uint32_t orb_lo = hard_l ? 0u : (uint32_t)orb, orb_hi = hard_l ? 0u : (uint32_t)(orb >> 32);
+        const uint32_t halt = hard_l ? lane : (nx & 0x7Fu);
+        lds_st4(arr + kGA, sw | (halt << 24), lw, orb_lo, orb_hi);
+        TSQ_TRACE(7, t);
+        TSQ_DELAY(5);
+        stage_publish(ctl, kCtlOrbitQ + (t & 3u), t + 1u, lane);
+        wbase = wbase + 256u >= StageCfg::WIN ? wbase + 256u - StageCfg::WIN : wbase + 256u;
+    }
+#ifdef TSQ_STATS
+    if (blockIdx.x == 0 && lane == 0 && which == 0u) { g_enc_stats[2] = st_[2]; g_enc_stats[3] = st_[3]; g_enc_stats[4] = TSQ_TOTAL(); g_enc_stats[6] = st_[6] + st_[5]; g_enc_stats[7] = TSQ_TOTAL(); }
+#endif
+}
+
 // ---- uniform (SGPR) flag arithmetic for the parser wave.  Flags are 0/1 integers and every select is an explicit
 //      s_cmp + s_cselect pair: left to itself the compiler keeps uniform booleans as 64-bit lane masks, selects through
 //      `s_and_b64 exec` triples and converts them to integers through a VGPR (v_cndmask + v_readfirstlane, ~30 cycles).
@@ -1019,7 +1230,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
     uint32_t cnt_[3] = {0, 0, 0};
 #endif
 #else
-    seen_v = ((volatile lds_u32_t*)ctl)[kCtlOrbitEven];
+    seen_v = ((volatile lds_u32_t*)ctl)[orbit_word<EXT, WINDOW>(0u)];
     load_record(recs + StageCfg::ARR + lane * 4u);
     asm volatile("" ::: "memory");
 #endif
@@ -1237,7 +1448,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
             REG_BEGIN(0); REG_END(0);
             REG_BEGIN(1);
             // (the serial stage polls without sleeping: a wake-up from s_sleep costs it up to 64 cycles per hand-off)
-            const uint32_t orbit_word = (t & 1u) ? kCtlOrbitOdd : kCtlOrbitEven;
+            const uint32_t orbit_at = orbit_word<EXT, WINDOW>(t);
             volatile lds_u32_t* arr = recs + rec_slot * StageCfg::REC_WORDS + StageCfg::ARR + lane * 4u;
             // The counter and the record's words were requested together at the end of the previous tile (in front of its publication's
             // bookkeeping): the LDS serves a wavefront's requests in order, so when the counter (asked for first) says the record is
@@ -1248,7 +1459,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
 #ifdef TSQ_STATS
                 const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
 #endif
-                while (!stage_ready(ctl, orbit_word, t + 1u)) { TSQ_SPIN(ctl); }
+                while (!stage_ready(ctl, orbit_at, t + 1u)) { TSQ_SPIN(ctl); }
 #ifdef TSQ_STATS
                 st_[8] += __builtin_amdgcn_s_memtime() - w0_;
 #endif
@@ -1460,7 +1671,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
 #ifdef TSQ_WALK_ASM
             asm_preload(next_slot * StageCfg::REC_WORDS * 4u, ((t & 1u) ? kCtlOrbitEven : kCtlOrbitOdd) * 4u);
 #else
-            seen_v = ((volatile lds_u32_t*)ctl)[(t & 1u) ? kCtlOrbitEven : kCtlOrbitOdd];
+            seen_v = ((volatile lds_u32_t*)ctl)[orbit_word_after<EXT, WINDOW>(t)];
             load_record(recs + next_slot * StageCfg::REC_WORDS + StageCfg::ARR + lane * 4u);
             asm volatile("" ::: "memory");
 #endif
@@ -2111,11 +2322,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void enc
     else if (role == kRoleTwins) stage_twins<WINDOW>(n, lds3, lane);
     else if (role == kRoleIn) stage_in<WINDOW>(n, lds3, lane);
     else if (role == kRoleNear) stage_near<EXT, WINDOW>(n, lds3, lane);
-    else if (role == kRoleMatch0 || role == kRoleMatch1) stage_match<EXT, WINDOW>(src, avail, n, table, lds3, lane, role == kRoleMatch1 ? 1u : 0u);
-    else if (role == kRoleOrbit0 || role == kRoleOrbit1) stage_orbit<EXT, WINDOW>(n, lds3, lane, role == kRoleOrbit1 ? 1u : 0u);
+    else if (!FusedMO<EXT, WINDOW>::value && (role == kRoleMatch0 || role == kRoleMatch1)) stage_match<EXT, WINDOW>(src, avail, n, table, lds3, lane, role == kRoleMatch1 ? 1u : 0u);
+    else if (!FusedMO<EXT, WINDOW>::value && (role == kRoleOrbit0 || role == kRoleOrbit1)) stage_orbit<EXT, WINDOW>(n, lds3, lane, role == kRoleOrbit1 ? 1u : 0u);
     else if (role == kRoleEmit) stream_emitter<StageCfg>(src, avail, out, lds3, lane, b, sizes, status);
     else if (role == kRoleBuilder) stream_builder<StageCfg>(lds3, lane, 0u);
     else if (role == kRoleBuilder1) stream_builder<StageCfg>(lds3, lane, 1u);
+    // (the fused form last in the chain, the pairs where they always were: the order of this chain decides where the compiler lays the
+    //  stages' code, and the headline kernel's layout is worth 0.4 ms)
+    else if (FusedMO<EXT, WINDOW>::value && (role == kRoleOrbit0 || role == kRoleOrbit1 || role == kRoleMatch0 || role == kRoleMatch1))
+        stage_match_orbit<EXT, WINDOW>(src, avail, n, table, lds3, lane, role == kRoleOrbit0 ? 0u : role == kRoleOrbit1 ? 1u : role == kRoleMatch0 ? 2u : 3u);   // (consecutive tiles on different SIMDs: 1, 2, 1, 2)
 #ifdef TSQ_SPINS
     if (blockIdx.x == 0 && lane == 0) g_enc_spins[threadIdx.x >> 6] = reinterpret_cast<uint32_t*>(stage_lds + StageCfg::off_ctl)[48u + (threadIdx.x >> 6)];
     if (blockIdx.x == 0 && role == kRoleEmit && lane == 0) for (uint32_t q = 0; q < 4u; ++q) g_enc_spins[16u + q] = reinterpret_cast<uint32_t*>(stage_lds + StageCfg::off_ctl)[44u + q];   // (EMIT leaves last)
