@@ -19,7 +19,7 @@ rows = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 ext = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 codec = tsq.DeviceCodec(0)
 kind = os.environ.get("TSQ_TRACE_KIND", "text")          # text | zeros | random | mix
-n_in = 10 ** 9 if kind == "text" else 1 << 30
+n_in = int(float(os.environ.get("TSQ_TRACE_BYTES", 10 ** 9 if kind == "text" else 1 << 30)))      # (more than 256 blocks: the lean layout, two blocks per CU)
 src = torch.from_numpy({"text": lambda: tsq.synth.text(n_in, 1), "zeros": lambda: np.zeros(n_in, dtype=np.uint8), "random": lambda: tsq.synth.random_bytes(n_in, 3),
                         "mix": lambda: tsq.synth.mix(n_in, 3)}[kind]()).cuda()
 out = torch.empty(api.container_bound(src.numel()), dtype=torch.uint8, device="cuda")
