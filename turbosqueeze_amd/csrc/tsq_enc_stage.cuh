@@ -1506,7 +1506,11 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                 // current.  The first such lane ends the segment; everything before it is exact.
                 const uint64_t seen = vall | V;
                 const uint32_t in_lo = tin_lo & (uint32_t)seen, in_hi = tin_hi & (uint32_t)(seen >> 32);
+#ifdef TSQ_X_NOHAZ      // timing only (wrong streams): no lane with a visited twin stops the walk -- what do the hazard lanes cost the pipeline?
+                uint64_t bad = 0;
+#else
                 uint64_t bad = __ballot((in_lo | in_hi | prev_hit) != 0u) & V;
+#endif
                 if (__builtin_expect((V & near_m) != 0ull, 0)) {
                     // near-twin lanes (classed "no match" on the assumption that a twin at most 3 back is visited) are
                     // the other way round: they are right exactly when such a twin was visited
