@@ -30,4 +30,5 @@ cp $S/spin_counts.txt profiles/${TAG}_encoder_spin_counts.txt
 ls -la profiles/${TAG}_*
 [ -f $S/tile_trace.txt ] && grep -v amdgpu.ids $S/tile_trace.txt > profiles/${TAG}_tile_trace.txt
 [ -f $S/sq_icache.txt ] && grep -v amdgpu.ids $S/sq_icache.txt > profiles/${TAG}_sq_icache.txt
+for f in tile_trace_zeros_ext1 tile_trace_lean_random_ext1 fuzz_variants; do [ -f $S/$f.txt ] && grep -v amdgpu.ids $S/$f.txt > profiles/${TAG}_$f.txt; done
 true
