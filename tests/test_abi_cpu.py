@@ -125,3 +125,18 @@ def test_pmc_summary_keys_by_kernel_and_launch_shape(tmp_path):
         assert got is None and "other kernel sources" in why
     finally:
         bench.ROOT = old_root
+
+
+def test_bench_gpus_n_refuses_a_node_with_fewer_gpus():
+    """`python bench.py --gpus 2` typed plainly is a launcher of two ranks; on a node that shows fewer than two GPUs it must exit
+    non-zero without printing a JSON line (a line that says n_gpus 1 for --gpus 2 must be impossible)."""
+    import sys
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs present")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TSQ_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "visible" in r.stderr

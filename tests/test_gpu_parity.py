@@ -557,21 +557,105 @@ def test_multi_workgroup_decode_beside_a_long_encode(tsq, oracle):
         dec.close()
 
 
-def test_bench_sharded_path_over_rccl_with_one_rank(tsq):
-    """bench.py's N > 1 step -- process group on the nccl (= RCCL) backend, all-gather of the sizes on the GPU, one host container in
-    /dev/shm registered with hipHostRegister, tsqa_sharded_place_async, tsqa_sharded_fetch_decode_async -- executed with a world of
-    ONE rank (the box has one GPU); the host-gathered container is compared with the oracle's inside bench.py."""
+def _run_bench(argv, env_extra, timeout=1200):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, TSQ_BENCH_FORCE_SHARDED="1", TSQ_BENCH_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533",
-               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--size", "300000000", "--no-weak"],
-                       env=env, capture_output=True, text=True, timeout=900)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_sharded_path_over_rccl_with_one_rank(tsq):
+    """bench.py's N > 1 line -- process group on the nccl (= RCCL) backend, all-gather of the sizes on the GPU, one host container in
+    /dev/shm registered with hipHostRegister, tsqa_sharded_place_async, tsqa_sharded_fetch_decode_async -- executed with a world of
+    ONE rank (the box has one GPU); the host-gathered container is compared with the oracle's inside bench.py."""
+    r, line = _run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--size", "300000000"],
+                         dict(TSQ_BENCH_FORCE_SHARDED="1", TSQ_BENCH_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533",
+                              RANK="0", LOCAL_RANK="0", WORLD_SIZE="1"), timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["config"]["container_equals_oracle"] is True and line["config"]["collective_backend"] == "nccl"
-    assert line["rank0_step_breakdown_ms"]["size_gather"] > 0
+    g = line["config4_host_gather"]
+    assert g["container_equals_oracle"] is True and g["collective_backend"] == "nccl" and g["scaling"] == "strong"
+    assert g["rank0_step_breakdown_ms"]["size_gather"] > 0
+    assert line["n_gpus"] == 1 and line["process_group_world_size"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["container_equals_oracle"] is True
+
+
+def test_bench_gpus_2_typed_plainly_launches_two_ranks(tsq):
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset) must start two ranks itself and say n_gpus 2 -- here
+    with both ranks on the box's one GPU over gloo (TSQ_BENCH_SHARE_GPU / TSQ_BENCH_BACKEND: the dry run of a 1-GPU box).  The line's
+    value is the weak-scaled one (two jobs), the config-4 section is the one job dealt b % 2 with its container equal to the
+    oracle's (the flag used to be parsed and ignored)."""
+    r, line = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--size", "150000000"],
+                         dict(TSQ_BENCH_SHARE_GPU="1", TSQ_BENCH_BACKEND="gloo"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["n_gpus"] == 2 and line["process_group_world_size"] == 2 and len(line["devices"]) == 2
+    assert sorted(d["rank"] for d in line["devices"]) == [0, 1]
+    assert line["distinct_devices"] == 1                                    # both ranks sat on GPU 0, and the line says so
+    assert line["scaling"] == "weak" and line["config"]["jobs"] == 2 and line["config"]["container_equals_oracle"] is True
+    assert line["value"] > 0 and abs(line["value"] - 2 * 150000000 / (line["ms_per_step"] * 1e-3) / 1e9) < 0.01 * line["value"] + 1e-3
+    g = line["config4_host_gather"]
+    assert g["container_equals_oracle"] is True and g["scaling"] == "strong" and g["collective_backend"] == "gloo"
+
+
+def test_bench_refuses_more_gpus_than_visible_and_a_world_that_is_not_gpus(tsq):
+    """--gpus N on a node with fewer than N GPUs exits non-zero without printing a line; so does a launcher that started another
+    number of ranks than --gpus says (a line whose n_gpus is not what was asked for must be impossible)."""
+    import torch
+    have = torch.cuda.device_count()
+    r, line = _run_bench(["--gpus", str(have + 1), "--steps", "1", "--warmup", "0", "--size", "50000000"], {}, timeout=600)
+    assert r.returncode != 0 and line is None, (r.returncode, r.stdout[-500:])
+    assert "visible" in r.stderr
+    r, line = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--size", "50000000"],
+                         dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29537"), timeout=600)
+    assert r.returncode != 0 and line is None, (r.returncode, r.stdout[-500:])
+
+
+def test_config4_eight_ranks_dealt_b_mod_8_host_container_equals_oracle(tsq, oracle):
+    """BASELINE config 4's own split at full size: the 10^9 B job, block b -> rank b % 8 (tsq_threads.cpp:71), through ShardedCodec --
+    eight 'ranks' (eight contexts on this GPU, in turn), every frame placed by tsqa_sharded_place_async in ONE host container, which
+    must be the oracle's container byte for byte; then every rank brings its frames back and decodes its 29 or 30 blocks (the
+    several-workgroups-per-block decoders: a GPU of the sharded job holds few blocks)."""
+    import torch
+    from turbosqueeze_amd import sharding
+    n, world, ext = 1_000_000_000, 8, 0
+    host = tsq.synth.text(n, seed=1)
+    want = oracle.compress(host, ext, threads=8)
+    hc = sharding.HostContainer("tsq_test_cfg4_%d" % os.getpid(), tsq.container_bound(n), create=True)
+    hc.register()
+    codecs = []
+    try:
+        lays = [sharding.ShardLayout(n, r, world) for r in range(world)]
+        assert sorted(b for l in lays for b in l.blocks) == list(range(239)) and all(l.blocks == list(range(l.rank, 239, 8)) for l in lays)
+        coders = []
+        all_sizes = np.zeros(lays[0].nb, dtype=np.uint32)
+        for r in range(world):
+            c = tsq.DeviceCodec(0)
+            codecs.append(c)
+            sc = sharding.ShardedCodec(lays[r], sharding.DeviceBlocks(c), hc, ext)
+            coders.append(sc)
+            d = to_dev(lays[r].pack_input(host))
+            sc.blocks.encode(d, lays[r].n_local, lays[r].stride, lays[r].last_len, ext)
+            sc.blocks.sync()
+            all_sizes[np.asarray(lays[r].blocks)] = sc.blocks.sizes_tensor().cpu().numpy().astype(np.uint32)[:lays[r].n_local]
+            del d
+        frame_at, total = sharding.frame_offsets(all_sizes)
+        for r in range(world):                            # rank 0 writes the header, every rank its own frames
+            assert coders[r].blocks.place(all_sizes, lays[r], ext, hc) == total
+            coders[r].blocks.sync()
+        assert total == len(want)
+        assert hc.array[:total].tobytes() == want
+        for r in range(world):
+            back = torch.empty(lays[r].shard_bytes, dtype=torch.uint8, device="cuda")
+            assert coders[r].decompress(total, back) == n
+            assert np.array_equal(back.cpu().numpy(), lays[r].expected_output(host)), r
+            del back
+    finally:
+        for c in codecs:
+            c.close()
+        hc.close()
 
 
 def test_decode_stall_is_not_a_stream_error_and_is_retried(tsq, oracle):

@@ -239,24 +239,36 @@ struct Sink {
     std::mutex alloc_m;
     size_t alloc_upto = 0;
     bool no_falloc = false;
-    bool ensure_allocated(size_t upto) {
+    // `ahead` = the call comes from the look-ahead thread (Prefault::start_mapped), which runs up to 1 GiB in front of the write
+    // cursor towards the job's BOUND: space it cannot get is space the job may never need, so its failure stops the look-ahead and
+    // nothing else.  Only the writer's own range failing (the exact bytes about to be copied) fails the job.
+    bool ensure_allocated(size_t upto, bool ahead = false) {
         if (!mapped) return true;
         std::lock_guard<std::mutex> g(alloc_m);
-        if (no_falloc || alloc_failed) return false;
         if (upto > cap) upto = cap;
+        if (upto <= alloc_upto) return true;                 // already backed, whatever happened further out
+        if (no_falloc || alloc_failed) return false;
         const size_t step = size_t(64) << 20;
         while (alloc_upto < upto) {
-            const size_t len = cap - alloc_upto < step ? cap - alloc_upto : step;
+            size_t len = cap - alloc_upto < step ? cap - alloc_upto : step;
+            if (ahead_refused && !ahead) len = upto - alloc_upto;   // the disk is nearly full: ask for what is written, not for a step
             int r;
             do r = fallocate(map_fd, 0, (off_t)alloc_upto, (off_t)len); while (r != 0 && errno == EINTR);
+            if (r != 0 && errno != EOPNOTSUPP && errno != ENOSYS && !ahead && len > upto - alloc_upto) {
+                len = upto - alloc_upto;                     // a whole step does not fit; the range being written may
+                do r = fallocate(map_fd, 0, (off_t)alloc_upto, (off_t)len); while (r != 0 && errno == EINTR);
+            }
             if (r != 0) {
-                if (errno == EOPNOTSUPP || errno == ENOSYS) no_falloc = true; else alloc_failed = true;
+                if (errno == EOPNOTSUPP || errno == ENOSYS) no_falloc = true;
+                else if (ahead) ahead_refused = true;
+                else alloc_failed = true;
                 return false;
             }
             alloc_upto += len;
         }
         return true;
     }
+    bool ahead_refused = false;                              // (under alloc_m)
     std::atomic<bool> alloc_failed{false};
     // small file outputs: collected like a memory sink, written once at the end.  Larger ones are MAPPED at their bound and
     // filled like memory too (pinned staging + a CPU copy into the page cache, whose pages a background fallocate provides ahead of
@@ -630,7 +642,7 @@ private:
         const std::vector<uint32_t> sizes = job_batches(nb, stage_in || stage_out, true);
         Marks mk; mk.at("compress: buffers opened");
         Prefault touch;
-        if (sink.mapped) touch.start_mapped([&sink](size_t upto) { return sink.ensure_allocated(upto); }, [&sink] { return sink.cursor.load(); }, sink.cap);
+        if (sink.mapped) touch.start_mapped([&sink](size_t upto) { return sink.ensure_allocated(upto, true); }, [&sink] { return sink.cursor.load(); }, sink.cap);
         else if (!stage_out) touch.start(sink.mem, sink.cap < total ? sink.cap : total);
         auto drain_one = [&]() {
             InFlight f = fly.front(); fly.pop_front();
@@ -877,7 +889,7 @@ private:
             if (!ok) break;
             if (bn == 0) { ok = false; break; }                        // truncated container
             // the result buffer is made resident only now that a first batch of frames has been found well formed
-            if (!touching && sink.mapped) { touch.start_mapped([&sink](size_t upto) { return sink.ensure_allocated(upto); }, [&sink] { return sink.cursor.load(); }, (size_t)total); touching = true; }
+            if (!touching && sink.mapped) { touch.start_mapped([&sink](size_t upto) { return sink.ensure_allocated(upto, true); }, [&sink] { return sink.cursor.load(); }, (size_t)total); touching = true; }
             if (!touching && !stage_out) { touch.start(sink.mem, (size_t)total); touching = true; }
             // the batch's frames are one contiguous slice of the container: the lane's device feeder reads it (file sources), copies
             // it to the device and launches the kernels

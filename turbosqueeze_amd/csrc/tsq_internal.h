@@ -27,7 +27,12 @@ struct tsqa_ctx {
     std::vector<uint64_t> host_frame_src;      // where each owned frame's stream starts in the host container
     hipEvent_t host_frames_copied = nullptr;   // recorded behind the descriptors' copy to the device
     bool host_frames_pending = false;
-    uint32_t sharded_n_local = 0;              // frames of the last tsqa_sharded_fetch_decode_async (tsqa_sharded_decode_again_async)
+    // what the last tsqa_sharded_fetch_decode_async left on the device for tsqa_sharded_decode_again_async: the descriptor count and
+    // the buffers they refer to.  Zero / null whenever `frames` may hold anything else (every other writer of `frames`, a reallocation).
+    uint32_t sharded_n_local = 0;
+    const void* sharded_streams = nullptr;
+    void* sharded_out = nullptr;
+    void forget_sharded() { sharded_n_local = 0; sharded_streams = nullptr; sharded_out = nullptr; }
     char probe_shape[160] = {0};               // what tsqa_measure_copy chose (tsqa_copy_probe_shape)
     uint32_t* duo_ring = nullptr;      // two-workgroup decoder: chunk records handed from the PARSE to the COPY workgroup of a block
     uint32_t* duo_flags = nullptr;     // and their progress counters

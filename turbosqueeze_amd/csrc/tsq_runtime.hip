@@ -102,6 +102,7 @@ int tsqa_ctx::reserve(size_t n_blocks, bool want_tables, bool want_slots)
         (void)hipStreamSynchronize(stream);
         (void)hipFree(sizes); (void)hipFree(frame_at); (void)hipFree(frames);
         sizes = nullptr; frame_at = nullptr; frames = nullptr; cap_blocks = 0;
+        forget_sharded();                                // (the descriptors of a sharded decode went with `frames`)
         TSQ_HIP(this, hipMalloc(&sizes, nb * sizeof(uint32_t)));
         TSQ_HIP(this, hipMalloc(&frame_at, (nb + 1) * sizeof(uint64_t)));
         TSQ_HIP(this, hipMalloc(&frames, nb * sizeof(FrameInfo)));
@@ -323,6 +324,7 @@ static int decompress_device_async_impl(tsqa_ctx* c, const void* d_in, size_t n,
     (void)hipSetDevice(c->device);
     int rc = c->reserve(n_blocks, false, false);
     if (rc) return rc;
+    c->forget_sharded();                                 // the frame walk below overwrites c->frames
     TSQ_HIP(c, hipMemsetAsync(d_status, 0, sizeof(int32_t), s));
     const bool timed = c->prof_begin(3, s);
     hipLaunchKernelGGL(frame_walk_kernel, dim3(1), dim3(64), 0, s, static_cast<const uint8_t*>(d_in), (uint64_t)n, n_blocks,
@@ -541,6 +543,7 @@ extern "C" int tsqa_sharded_fetch_decode_async(tsqa_ctx* c, const void* host_con
     // buffers can hold -- before a single copy is enqueued (a container with more, shorter blocks than the job the buffers were sized
     // for must not overrun them).
     if ((uint64_t)n_local * kSlotSize > streams_cap) { c->set_error("sharded_fetch_decode: %u owned frames do not fit d_streams (%zu B)", n_local, streams_cap); return TSQA_ERR_FORMAT; }
+    c->forget_sharded();                                 // whatever happens below, an older call's descriptors are not to be decoded again
     if (int rc = c->reserve(n_local ? n_local : 1, false, false)) return rc;
     if (int rc = c->reserve_host_frames(n_local ? n_local : 1)) return rc;
     uint64_t at = 16, sum = 0;
@@ -573,7 +576,7 @@ extern "C" int tsqa_sharded_fetch_decode_async(tsqa_ctx* c, const void* host_con
     TSQ_HIP(c, hipMemcpyAsync(c->frames, c->host_frames, (size_t)n_local * sizeof(FrameInfo), hipMemcpyHostToDevice, s));
     TSQ_HIP(c, hipEventRecord(c->host_frames_copied, s));
     c->host_frames_pending = true;
-    c->sharded_n_local = n_local;
+    c->sharded_n_local = n_local; c->sharded_streams = d_streams; c->sharded_out = d_out;
     return c->launch_decode_frames(d_streams, c->frames, n_local, d_out, d_status, s);
 }
 
@@ -584,7 +587,9 @@ extern "C" int tsqa_sharded_decode_again_async(tsqa_ctx* c, const void* d_stream
 {
     if (!c) return TSQA_ERR_ARG;
     if (!d_streams || !d_out || !d_status) { c->set_error("sharded_decode_again: null pointer"); return TSQA_ERR_ARG; }
-    if (c->sharded_n_local == 0) { c->set_error("sharded_decode_again: no sharded decode to repeat on this context"); return TSQA_ERR_ARG; }
+    if (c->sharded_n_local == 0) { c->set_error("sharded_decode_again: no sharded decode to repeat on this context (none yet, or another call has used the context since)"); return TSQA_ERR_ARG; }
+    // the descriptors hold offsets into the buffers of THAT call: a retry into other buffers would decode them against the wrong memory
+    if (d_streams != c->sharded_streams || d_out != c->sharded_out) { c->set_error("sharded_decode_again: not the buffers of the sharded decode being repeated"); return TSQA_ERR_ARG; }
     hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
     (void)hipSetDevice(c->device);
     TSQ_HIP(c, hipMemsetAsync(d_status, 0, sizeof(int32_t), s));
