@@ -76,6 +76,12 @@ size_t tsqa_block_count(size_t n);
  * 16 + n_blocks * (3 + TSQ_OUTPUT_SZ)  (tsq_threads.cpp:339). */
 size_t tsqa_container_bound(size_t n);
 
+/* What this library was compiled as: a static string of the form
+ *   "arch=gfx950 timing_only=0 instrumented=0 ab_variants=0 lm=4 lf=3 records=11 [switches: none]"
+ * timing_only = 1 means a TSQ_X_* switch that gives WRONG streams on purpose (an experiment library, csrc/tsq_experiment.h);
+ * the product library always reports timing_only=0 instrumented=0 and "switches: none" (tests/test_abi_cpu.py asserts it). */
+const char* tsqa_build_info(void);
+
 /*
  * Compress n bytes resident at d_in into a complete .tsq container at d_out
  * (header "TSQ1" | u32 n_blocks | u64 n, then per block u24 (size | ext<<23) + stream;

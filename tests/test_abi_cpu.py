@@ -140,3 +140,19 @@ def test_bench_gpus_n_refuses_a_node_with_fewer_gpus():
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert "visible" in r.stderr
+
+
+def test_product_library_carries_no_experiment_switch():
+    """tsqa_build_info(): the product library was compiled without any timing-only (wrong streams on purpose) or instrumentation
+    switch; a build that passes one without -DTSQ_EXPERIMENT does not compile (csrc/tsq_experiment.h)."""
+    info = tsq.build_info()
+    assert "timing_only=0" in info and "instrumented=0" in info and "ab_variants=0" in info and "[switches: none]" in info, info
+    assert "timing_only=0" in tsq.build_info(ab=True) and "ab_variants=1" in tsq.build_info(ab=True)
+    assert "TSQ_JITTER" in tsq.build_info(ab="jitter") and "timing_only=0" in tsq.build_info(ab="jitter")
+    csrc = os.path.join(ROOT, "turbosqueeze_amd", "csrc")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-DTSQ_X_NOHAZ", os.path.join(csrc, "tsq_runtime.hip")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "TSQ_EXPERIMENT" in r.stderr, r.stderr[-500:]
+    # and the encoder source carries only the guarded timing-only sites (VERDICT r05 item 6)
+    src = open(os.path.join(csrc, "tsq_enc_stage.cuh")).read()
+    assert sum("TSQ_X_" in ln for ln in src.splitlines()) <= 10

@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../turbosqueeze_amd/csrc"
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $flags -shared -o ../libturbosqueeze_amd_x_$name.so tsq_runtime.hip tsq_compat.hip -lpthread &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DTSQ_EXPERIMENT $flags -shared -o ../libturbosqueeze_amd_x_$name.so tsq_runtime.hip tsq_compat.hip -lpthread &
 done
 wait
 ls -la ../libturbosqueeze_amd_x_*.so

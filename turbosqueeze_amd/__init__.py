@@ -9,6 +9,7 @@ from .api import (  # noqa: F401
     OUTPUT_SZ,
     DeviceCodec,
     TsqError,
+    build_info,
     build_native,
     container_bound,
     lib,

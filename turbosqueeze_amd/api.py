@@ -58,6 +58,11 @@ def source_fingerprint() -> str:
     return h.hexdigest()[:16]
 
 
+def build_info(ab=False) -> str:
+    """tsqa_build_info() of a library: which experiment / instrumentation switches it was compiled with (the product: none)."""
+    return lib(ab).tsqa_build_info().decode()
+
+
 _libs = {}
 
 
@@ -81,6 +86,8 @@ def lib(ab=False) -> C.CDLL:
     L.tsqa_device_id.argtypes = [vp]
     L.tsqa_block_count.restype = C.c_size_t
     L.tsqa_block_count.argtypes = [C.c_size_t]
+    L.tsqa_build_info.restype = C.c_char_p
+    L.tsqa_build_info.argtypes = []
     L.tsqa_container_bound.restype = C.c_size_t
     L.tsqa_container_bound.argtypes = [C.c_size_t]
     L.tsqa_compress_device.restype = C.c_int

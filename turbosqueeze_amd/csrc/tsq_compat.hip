@@ -574,6 +574,10 @@ private:
     //  it is written, and a piece's write wants tens of megabytes to be worth its threads)
     static uint32_t progress_piece(uint32_t n_blocks, bool staged = false) {
         if (staged && n_blocks >= 32) return n_blocks / 4;
+        // a staged (file) batch below 32 blocks still goes in at least two pieces, so that the next piece comes back while this one is
+        // written and the per-block progress calls do not arrive as one burst per batch (the reference reports a block as it lands,
+        // tsq_threads.cpp:248-254)
+        if (staged && n_blocks >= 2) return (n_blocks + 1) / 2 < 8u ? (n_blocks + 1) / 2 : 8u;
         // (a copy to pageable memory has a fixed cost of its own -- the runtime locks and unlocks the pages around it --: 8 MB pieces came
         //  back at 17-26 GB/s where 32-64 MB pieces reach the link's 46-50)
         return n_blocks >= 32 ? 16u : n_blocks >= 16 ? 8u : n_blocks;

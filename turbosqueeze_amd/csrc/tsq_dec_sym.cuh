@@ -79,10 +79,14 @@ struct SymLds {
     // the same time): the NEXT chunk's stream is staged, and every offset of it parsed as a group start, while the
     // current chunk's bytes are being resolved -- `stage` lies behind the symbol records in the part of the doubling tables that is dead
     // during the copy phases, `j1x` (next - offset of the chunk after) behind the ring, where nothing overwrites it until its chunk is parsed.
+#ifdef TSQ_DEC_PIPE
     static constexpr uint32_t stage = recw + 4 * (SymCfg::OUTC + 16);                // u8[S + SPAD + 16]: the next chunk's stream (P5 of this one)
     static constexpr uint32_t j1x = ring + SymCfg::R + SymCfg::RPAD;                 // u8[S]
     static constexpr uint32_t total = j1x + SymCfg::S;
     static_assert(stage % 16 == 0 && stage + 16 * SymCfg::SWORDS <= gstart, "the staged stream fits behind the records");
+#else
+    static constexpr uint32_t total = ring + SymCfg::R + SymCfg::RPAD;               // (the product asks for nothing it does not use)
+#endif
     static_assert(SymCfg::R % 16 == 0, "ring phase");
     static_assert(recw % 16 == 0 && recw + 4 * (SymCfg::OUTC + 16) <= gstart && plist % 16 == 0 && plist + 2 * SymCfg::OUTC <= gstart,
                   "records, byte entries and waiting lists fit the dead doubling tables");
@@ -347,20 +351,14 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
             misc[0] = k;
             if (k >= C::MAXSN && x < slim) misc[4] = kErrStream;
         }
-#ifdef TSQ_X_DEC_FLUSH_P3
-        if (tid >= 64u) flush_image(64u, C::T - 64u);
-#endif
         __syncthreads();
         const uint32_t nsn = misc[0];
         TSQD_ACC(3);
 
         // ---------------- P4: one lane per group.  Group 16 k + r starts where r's bits lead from super node k.
         // (The upper half of the workgroup has no group to look after: it writes the PREVIOUS chunk's bytes to HBM meanwhile -- P7.)
-#ifdef TSQ_X_DEC_FLUSH_P3     // (experiment: the previous chunk's image goes out beside the single-lane chain of P3 instead of beside P4's groups)
-#elif defined(TSQ_X_DEC_NOFLUSH)   // (timing only, wrong output: what does the flush cost P4?)
-#else
+        // (measured in round 5: a build without this flush runs 4.558 against 4.553 ms, the flush beside P3's chain instead 4.572 -- it hides completely)
         if (tid >= C::T / 2) flush_image(C::T / 2, C::T / 2);
-#endif
         {
             uint32_t x = C::TERM;
             if (tid < nsn * C::HOP) {

@@ -56,6 +56,7 @@
 #endif
 
 #include "tsq_common.cuh"
+#include "tsq_experiment.h"
 #include "tsq_enc_util.cuh"
 #include "tsq_enc_builder.cuh"
 
@@ -80,35 +81,31 @@ struct StageCfgT {
     static constexpr uint32_t RING = 256;                          // symbol records between BUILDER and EMIT (four batches)
     static constexpr uint32_t LM = WINDOW ? TSQ_LM : TSQ_LM_LEAN, LF = WINDOW ? TSQ_LF : TSQ_LF_LEAN;
     static_assert((LM == 3u || LM == 4u) && LF >= 2u && LF < LM, "lags");
-#ifndef TSQ_X_R
-#define TSQ_X_R 11
+#ifndef TSQ_RECORDS
+#define TSQ_RECORDS 11
 #endif
     // tile records in flight (HASH runs at most R - LM tiles ahead of WALK).  Measured in the standard layout: 9 records 44.5 ms, 10 41.9,
     // 11 41.1, 12 41.5, 13 41.1, 14 41.4 (the even counts, where the even and the odd tiles' wavefronts keep to their own slots, are the
     // slower ones); the eleventh record has the room the input window's margin gave up.  The lean layout: 9, 10 or 11 make no difference.
-    static constexpr uint32_t R = LM == 3u ? (WINDOW ? 10 : 8) : (WINDOW ? TSQ_X_R : 10);
-#ifndef TSQ_X_OWNBITS
-#define TSQ_X_OWNBITS 15
+    static constexpr uint32_t R = LM == 3u ? (WINDOW ? 10 : 8) : (WINDOW ? TSQ_RECORDS : 10);
+#ifndef TSQ_OWNBITS
+#define TSQ_OWNBITS 15
 #endif
-    static constexpr uint32_t OWN_MASK = (WINDOW ? TSQ_X_OWNBITS == 15 : LM == 3u) ? 0x7FFFu : 0x3FFFu;   // owner image: hash folded to 15 bits (14 in the lean layout when it keeps ten records)
+    static constexpr uint32_t OWN_MASK = (WINDOW ? TSQ_OWNBITS == 15 : LM == 3u) ? 0x7FFFu : 0x3FFFu;   // owner image: hash folded to 15 bits (14 in the lean layout when it keeps ten records)
     // input window ring: the last 64 KiB of input and what HASH may be ahead of MATCH and WALK: while they work on tile t, WALK has not
     // finished it, so HASH is at tile t + R - LM at most -- 64 KiB + 7 tiles + a tile's own 64 bytes = 66 047; a multiple of 64
-#ifndef TSQ_X_WIN
-#define TSQ_X_WIN 66560
+#ifndef TSQ_WIN
+#define TSQ_WIN 66560
 #endif
-    static constexpr uint32_t WIN = TSQ_X_WIN;
-    static_assert(WIN % 64u == 0u && WIN > 65536u + (TSQ_X_R - 3u) * 64u + 63u, "window margin");
+    static constexpr uint32_t WIN = TSQ_WIN;
+    static_assert(WIN % 64u == 0u && WIN > 65536u + (TSQ_RECORDS - 3u) * 64u + 63u, "window margin");
     static constexpr uint32_t W16 = 16;                           // word offset of the uint4-per-lane input words
     static constexpr uint32_t ARR = 16 + 256;                     // word offset of the per-lane words: four groups of four words per lane
     static constexpr uint32_t REC_WORDS = ARR + 16 * 64;
     // bucket of a hash in the owner image: the top bits of a 32-bit multiplicative hash.  (Masking the 17-bit hash drops two bits that
     // carry entropy on text: 1.6 lanes per tile met another hash in their bucket, three times what 256 live entries make likely, and
     // every one costs TWINS a round of ballots: 44.0 -> 43.5 ms.)
-#ifdef TSQ_X_MASKFOLD
-    static __device__ __forceinline__ uint32_t fold(uint32_t h) { return h & OWN_MASK; }
-#else
     static __device__ __forceinline__ uint32_t fold(uint32_t h) { return (h * 0x9E3779B1u) >> (OWN_MASK == 0x7FFFu ? 17 : 18); }
-#endif
     static constexpr uint32_t off_owner = 0;                                   // u8[OWN_MASK + 1]
     static constexpr uint32_t off_queue = OWN_MASK + 1u;                       // u32[Q * ITEM_WORDS]
     static constexpr uint32_t off_ring = off_queue + Q * ITEM_WORDS * 4;       // u32[RING]
@@ -272,10 +269,10 @@ __device__ __forceinline__ void stage_hash(const uint8_t* src, uint64_t avail, u
     TSQ_BEGIN();
     // The input words are requested D tiles ahead: every other tile starts a new 128-byte line that comes from HBM (two microseconds,
     // more than a tile period), and this wavefront feeds every other stage.
-#ifndef TSQ_X_HD
-#define TSQ_X_HD 4
+#ifndef TSQ_HASH_AHEAD
+#define TSQ_HASH_AHEAD 4
 #endif
-    constexpr uint32_t D = TSQ_X_HD;                     // tiles the input words are requested ahead
+    constexpr uint32_t D = TSQ_HASH_AHEAD;                     // tiles the input words are requested ahead
     uint4 w_q[D];
 #pragma unroll
     for (uint32_t d = 0; d < D; ++d) w_q[d] = ld128z(src, (uint64_t)lane + 64u * d, avail);
@@ -289,10 +286,6 @@ __device__ __forceinline__ void stage_hash(const uint8_t* src, uint64_t avail, u
         TSQ_TRACE(0, t);
         const uint32_t h = hash4(w16.x);
         const uint32_t hf = StageCfg::fold(h);
-#ifdef TSQ_X_TBL_PREFETCH
-        // the table line MATCH will gather from a few tiles from now is pulled into the L2 already (the value is not used)
-        if (!WINDOW || TSQ_X_TBL_PREFETCH > 1) { const uint32_t pf = table[h]; asm volatile("" :: "v"(pf)); }
-#endif
         // The owner image: per folded hash, the last lane that had it and the low two bits of its tile number.  Nothing is ever
         // retired: an entry is taken for what it says -- a lane one to four tiles back -- and TWINS checks it against that lane's own
         // hash: a lane that really owns the bucket has this folded hash; the zero the image starts with and entries older than four
@@ -560,9 +553,6 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         if (t >= LM + 1u && !stage_wait_seen(ctl, kCtlCommitted, t - LM, committed_seen, 3)) break;
 #endif
         TSQ_TRACE(10, t);
-#ifdef TSQ_X_EXTRA_GATHER   // perturbation (streams unchanged): a second, equally cold gather per lane -- what the table's line traffic costs shows as the slowdown
-        const uint32_t tv_extra = table[h ^ 0x1AAAAu];
-#endif
 #ifdef TSQ_X_FAKE_TABLE   // timing only (wrong streams): every gather hits 512 bytes of the table
         const uint32_t tv_old = table[h & 0xFFu];
 #else
@@ -600,12 +590,6 @@ __device__ __forceinline__ void stage_match(const uint8_t* src, uint64_t avail, 
         // ---- candidates of tile t
         const uint32_t p = (t << 6) + lane;
         const uint32_t cand0 = candidate_of(tv, p);
-#ifdef TSQ_X_EXTRA_GATHER
-        asm volatile("" :: "v"(tv_extra));
-#endif
-#ifdef TSQ_X_EXTRA_CAND      // perturbation: a second 16-byte gather per lane from a cold line of the input window
-        { const uint4 xb = ld128z(src, (uint64_t)((cand0 ^ 0x5555u) & 0x3FFFFFu) < avail ? (cand0 ^ 0x5555u) & 0x3FFFFFu : 0u, avail); asm volatile("" :: "v"(xb.x), "v"(xb.y), "v"(xb.z), "v"(xb.w)); }
-#endif
         MREG_BEGIN(13);
         // their 16 bytes come from the window ring in LDS (SCAN has written everything below (t+1)*64); the few lanes whose
         // candidate ends beyond that (closer than 19 bytes to the tile's end) gather from global memory
@@ -880,7 +864,7 @@ __device__ __forceinline__ void stage_orbit(uint32_t n, lds_u8_t* lds, uint32_t 
 // the one the headline runs (no extensions, window in LDS), where the pairs are 0.7 % faster.  The late classification runs behind
 // MATCH's here (in front of the gather's use it costs text 0.5 ms).  (The two forms share no helper functions on purpose: the same
 // statements moved into inlined helpers came out 0.45 ms slower for the pairs and 2.5 ms slower in the lean layout -- scheduling.)
-#if defined(TSQ_FUSED_OFF) || defined(TSQ_WALK_ASM_ON)
+#if defined(TSQ_FUSED_OFF)
 template <bool EXT, bool WINDOW> struct FusedMO { static constexpr bool value = false; };
 #elif defined(TSQ_FUSED_ALL)
 template <bool EXT, bool WINDOW> struct FusedMO { static constexpr bool value = true; };
@@ -1192,254 +1176,11 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
         if (LM == 4u) { const u32x2_t gd = lds_ld2(arr + kGD); tp3r_lo = gd.x; tp3r_hi = gd.y; }
         nx = spanword >> 24;
     };
-    // ---- (Experiment, off by default: -DTSQ_WALK_ASM_ON.  Measured on the MI355X: 39.9 ms per 1e9 B with it against 39.2 without -- it walks
-    //       80 % of the tiles by itself, but what paces the pipeline once ACCOUNT is out of the way is the lag loop WALK -> COMMIT -> MATCH ->
-    //       ORBIT -> WALK, not the serial stage's instruction count)
-    //      The usual tile in one hand-written block (TSQ_WALK_ASM): ORBIT has published the tile, the orbit from the entry lane meets no
-    // lane with a visited twin and no near-twin lane, and leaves the tile.  The block does what the loop body below does for such a tile
-    // -- prologue masks, three v_readlane, the test for visited twins, the last match, the visited mask for MATCH / COMMIT / ACCOUNT, the
-    // tile counter, the request for the next tile's record -- in about seventy instructions and three not-taken branches (the compiled
-    // body: about a hundred and eight branches).  Anything else leaves it with nothing changed (code != 0) and goes through the compiled
-    // body.  The tile record lives in FIXED vector registers between the request at the end of a tile and its use in the next one:
-    // v[48:51] group A (spanword, lane word, orbit lo / hi), v[52:55] group B (near word, hash, twins in the tile lo / hi), v[56:59] group C
-    // (twins in t-1, t-2), v[60:61] group D (twins in t-3), v62 ORBIT's counter as read in front of them; s[60:83], v[40:47] and v63 are scratch.
-#if defined(TSQ_WALK_ASM_ON) && !defined(TSQ_STATS) && !defined(TSQ_SPINS) && !defined(TSQ_REGION)
-#define TSQ_WALK_ASM 1
-    static_assert(LM == 4u && LF == 3u, "the hand-written tile assumes the lags it was written for");
-    const uint32_t lds0 = (uint32_t)(size_t)lds;
-    const uint32_t a_ctl = lds0 + StageCfg::off_ctl;                                                   // ctl[0]
-    const uint32_t a_vis = lds0 + StageCfg::off_rec + 8u + (lane & 1u) * 4u;                           // record word 2 / 3
-    const uint32_t a_arr = lds0 + StageCfg::off_rec + StageCfg::ARR * 4u + lane * 16u;                 // group A of this lane
-    const uint32_t sh32 = (lane & 1u) << 5;
-    // the record in slot_bytes and the counter word at ctl byte offset ctr, into the fixed registers
-    auto asm_preload = [&](uint32_t slot_bytes, uint32_t ctr) {
-        asm volatile(
-            "v_mov_b32_e32 v45, %[actl]\n\t"
-            "v_add_u32_e32 v46, %[sb], %[aarr]\n\t"
-            "v_add_u32_e32 v45, %[ctr], v45\n\t"
-            "ds_read_b32 v62, v45\n\t"
-            "ds_read_b128 v[48:51], v46\n\t"
-            "ds_read_b128 v[52:55], v46 offset:1024\n\t"
-            "ds_read_b128 v[56:59], v46 offset:2048\n\t"
-            "ds_read_b64 v[60:61], v46 offset:3072"
-            :: [actl] "s"(a_ctl), [sb] "s"(uniform(slot_bytes)), [ctr] "s"(uniform(ctr)), [aarr] "v"(a_arr)
-            : "memory", "v45", "v46", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62");
-    };
-    asm_preload(0u, kCtlOrbitEven * 4u);
-#ifdef TSQ_X_WALK_COUNT
-    uint32_t cnt_[3] = {0, 0, 0};
-#endif
-#else
     seen_v = ((volatile lds_u32_t*)ctl)[orbit_word<EXT, WINDOW>(0u)];
     load_record(recs + StageCfg::ARR + lane * 4u);
     asm volatile("" ::: "memory");
-#endif
     TSQ_BEGIN();
     for (uint32_t t = 0; done == 0u; ++t, wbase = wbase + 64u == StageCfg::WIN ? 0u : wbase + 64u, rec_slot = rec_slot + 1u == StageCfg::R ? 0u : rec_slot + 1u) {
-#ifdef TSQ_WALK_ASM
-        uint32_t code, L_o, prev_hit_o;
-        uint64_t near_o, cert_o, V_o;
-#ifdef TSQ_X_WALK_COUNT
-        static_assert(true, "");
-#endif
-        {
-            TSQ_TRACE_ALL(8, t);                          // (with the hand-written tile: in front of its wait for ORBIT)
-            TSQ_JIT((t + 1u) * 64u + 5u);
-            TSQ_DELAY(6);
-            // (the compiler carries these two round the loop in vector registers -- it takes them for lane-dependent behind the hazard loop's exits)
-            uint32_t v_u = uniform(v), lm_u = uniform(last_m);
-            asm volatile(
-                "s_add_i32 s61, %[t], 1\n\t"
-                "s_lshl_b32 s62, %[t], 6\n\t"                      // base
-                "s_waitcnt lgkmcnt(4)\n\t"                         // ORBIT's counter, requested at the end of the previous tile in front of the record
-                "v_readfirstlane_b32 s60, v62\n\t"
-                "s_mul_i32 s81, %[slot], %[recb]\n\t"
-                "s_cmp_lt_u32 s60, s61\n\t"
-                "v_add_u32_e32 v63, s81, %[aarr]\n\t"              // this lane's group A in the tile's record
-                "s_cbranch_scc0 2f\n\t"
-                // ---- ORBIT has not published the tile yet: poll its counter (no sleep: the serial stage), then take the record again
-                "s_bitcmp1_b32 %[t], 0\n\t"
-                "s_cselect_b32 s83, %[codd], %[ceven]\n\t"
-                "v_mov_b32_e32 v45, %[actl]\n\t"
-                "v_add_u32_e32 v45, s83, v45\n"
-                "1:\n\t"
-#ifdef TSQ_X_WALK_SLEEP
-                "s_sleep 1\n\t"
-#endif
-                "ds_read_b32 v62, v45\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "v_readfirstlane_b32 s60, v62\n\t"
-                "s_cmp_lt_u32 s60, s61\n\t"
-                "s_cbranch_scc1 1b\n\t"
-                "ds_read_b128 v[48:51], v63\n\t"
-                "ds_read_b128 v[52:55], v63 offset:1024\n\t"
-                "ds_read_b128 v[56:59], v63 offset:2048\n\t"
-                "ds_read_b64 v[60:61], v63 offset:3072\n\t"
-                "s_waitcnt lgkmcnt(0)\n"
-                "2:\n\t"
-                // ---- the tile's prologue: lanes with a twin visited in the previous tiles, near-twin lanes, certain matches
-                "s_sub_i32 s66, %[v], s62\n\t"                     // entry lane
-                "s_mov_b64 s[68:69], %[p1]\n\t"
-                "s_mov_b64 s[70:71], %[p2]\n\t"
-                "s_mov_b64 s[72:73], %[p3]\n\t"
-                "s_waitcnt lgkmcnt(3)\n\t"                         // group A has arrived (the groups come back in the order they were asked for)
-                "v_lshrrev_b32_e32 v47, 24, v48\n\t"               // where the orbit from each lane halts
-                "v_bfe_u32 v41, v48, 12, 1\n\t"
-                "v_bfe_u32 v46, v48, 11, 1\n\t"
-                "v_bfe_u32 v44, v48, 10, 1\n\t"
-                "v_add_u32_e32 v41, -1, v41\n\t"                   // all ones unless ORBIT settled the lane's twins in t-3
-                "v_cmp_ne_u32_e64 %[nearm], 0, v46\n\t"
-                "v_cmp_ne_u32_e64 %[certm], 0, v44\n\t"
-                "s_waitcnt lgkmcnt(1)\n\t"                         // groups B, C
-                "v_and_b32_e32 %[ph], s68, v56\n\t"                // twins in t-1 that were visited
-                "v_and_b32_e32 v45, s69, v57\n\t"
-                "v_and_or_b32 %[ph], v58, s70, %[ph]\n\t"          // ... in t-2
-                "v_and_or_b32 v45, v59, s71, v45\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"                         // group D
-                "v_and_b32_e32 v42, v60, v41\n\t"
-                "v_and_b32_e32 v43, v61, v41\n\t"
-                "v_and_or_b32 %[ph], v42, s72, %[ph]\n\t"          // ... in t-3
-                "v_and_or_b32 v45, v43, s73, v45\n\t"
-                "v_or_b32_e32 %[ph], %[ph], v45\n\t"
-                "s_mov_b64 %[Vo], 0\n"
-                // ---- one segment: the orbit from lane s66, up to its first lane whose gathered candidate is stale
-                "4:\n\t"
-                "v_readlane_b32 s64, v50, s66\n\t"
-                "v_readlane_b32 s65, v51, s66\n\t"                 // V = s[64:65]: the lanes the orbit visits
-                "v_readlane_b32 s67, v47, s66\n\t"                 // where it halts (64 and above: past the tile)
-                "s_mov_b32 %[code], 2\n\t"
-                "s_mov_b32 %[Lo], s66\n\t"
-                "s_or_b64 s[74:75], %[Vo], s[64:65]\n\t"           // everything visited so far in the tile
-                "s_and_b64 s[76:77], %[nearm], s[64:65]\n\t"
-                "s_cbranch_scc1 9f\n\t"                            // a near-twin lane on the orbit: the compiled segment takes it from here
-                "v_and_b32_e32 v44, s74, v54\n\t"                  // twins earlier in this tile that were visited
-                "v_and_or_b32 v44, v55, s75, v44\n\t"
-                "v_or_b32_e32 v44, v44, %[ph]\n\t"
-                "v_cmp_ne_u32_e64 s[74:75], 0, v44\n\t"            // lanes with a visited twin
-                "s_and_b64 s[74:75], s[74:75], s[64:65]\n\t"       // ... on the orbit
-                "s_cbranch_scc0 3f\n\t"
-                "s_ff1_i32_b64 s67, s[74:75]\n\t"                  // the first of them ends the segment; everything before it is exact
-                "s_bfm_b64 s[76:77], s67, 0\n\t"
-                "s_and_b64 s[64:65], s[64:65], s[76:77]\n"
-                "3:\n\t"
-                "s_and_b64 s[76:77], s[64:65], %[certm]\n\t"       // visited match lanes
-                "s_flbit_i32_b64 s74, s[76:77]\n\t"
-                "s_add_i32 s75, s62, 63\n\t"
-                "s_sub_i32 s74, s75, s74\n\t"
-                "s_cmp_lg_u64 s[76:77], 0\n\t"
-                "s_cselect_b32 %[lastm], s74, %[lastm]\n\t"
-                "s_or_b64 %[Vo], %[Vo], s[64:65]\n\t"
-                "s_mov_b32 s66, s67\n\t"
-                "s_add_i32 %[v], s62, s67\n"
-                "5:\n\t"
-                "s_cmp_lt_u32 s66, 64\n\t"
-                "s_cbranch_scc0 7f\n\t"                            // the walk has left the tile
-                // ---- a hazard lane (s66).  Its nearest twin and the common prefix with it are in NEAR's word: if that twin was visited it IS
-                //      the candidate, and if no pair origin can matter (the last match starts at or behind candidate + length) the lane is
-                //      decided here; anything else goes to the compiled hazard loop.
-                "s_mov_b32 %[code], 1\n\t"
-                "s_mov_b32 %[Lo], s66\n\t"
-                "v_readlane_b32 s67, v52, s66\n\t"                 // bit 15 valid | tiles back << 12 | twin's lane << 6 | prefix
-                "s_add_i32 s63, s62, s66\n\t"                      // i
-                "s_mov_b64 s[78:79], %[Vo]\n\t"
-                "s_bfe_u32 s76, s67, 0x2000c\n\t"                  // tiles back
-                "s_bfe_u32 s77, s67, 0x60006\n\t"                  // twin's lane
-                "s_cmp_eq_u32 s76, 1\n\t"
-                "s_cselect_b64 s[78:79], s[68:69], s[78:79]\n\t"
-                "s_cmp_eq_u32 s76, 2\n\t"
-                "s_cselect_b64 s[78:79], s[70:71], s[78:79]\n\t"
-                "s_cmp_eq_u32 s76, 3\n\t"
-                "s_cselect_b64 s[78:79], s[72:73], s[78:79]\n\t"
-                "s_lshr_b64 s[78:79], s[78:79], s77\n\t"
-                "s_lshr_b32 s80, s67, 15\n\t"
-                "s_and_b32 s80, s80, s78\n\t"
-                "s_bitcmp1_b32 s80, 0\n\t"
-                "s_cbranch_scc0 9f\n\t"                            // no word, or the nearest twin was not visited
-                "s_lshl_b32 s76, s76, 6\n\t"
-                "s_and_b32 s83, s67, 63\n\t"                       // k
-                "s_sub_i32 s82, s62, s76\n\t"
-                "s_max_u32 s74, s83, 4\n\t"                        // need
-                "s_add_i32 s82, s82, s77\n\t"                      // candidate
-                "s_add_i32 s75, s82, s74\n\t"
-                "s_cmp_ge_u32 %[lastm], s75\n\t"
-                "s_cbranch_scc0 9f\n\t"
-                "s_cmp_lt_u32 s63, %[tail]\n\t"
-                "s_cbranch_scc0 9f\n\t"
-                "s_sub_i32 s75, s63, s82\n\t"
-                "s_cmp_lt_u32 s75, 0xff00\n\t"
-                "s_cbranch_scc0 9f\n\t"
-                "s_cmp_ge_u32 s83, 4\n\t"                          // a match?
-                "s_cselect_b32 s76, 0x400, 0\n\t"
-                "s_cselect_b32 s77, s74, 1\n\t"                    // span
-                "s_cselect_b32 %[lastm], s63, %[lastm]\n\t"
-                "s_add_i32 s78, s74, -1\n\t"                       // nibble (tsq_encode.cpp:44-45: mlen[k] = k - 1 below 17)
-                "s_or_b32 s79, s77, s76\n\t"
-                "s_lshl_b32 s78, s78, 24\n\t"
-                "s_lshl_b64 s[74:75], 1, s66\n\t"
-                "s_or_b32 s80, s82, s78\n\t"
-                "s_mov_b64 exec, s[74:75]\n\t"                     // the lane's class goes into the tile's record (ACCOUNT reads it there)
-                "v_and_b32_e32 v40, 0xfffffb00, v48\n\t"
-                "v_mov_b32_e32 v41, s80\n\t"
-                "v_or_b32_e32 v40, s79, v40\n\t"
-                "s_nop 0\n\t"
-                "ds_write_b64 v63, v[40:41]\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "s_or_b64 %[Vo], %[Vo], s[74:75]\n\t"
-                "s_add_i32 %[v], s63, s77\n\t"
-                "s_sub_i32 s66, %[v], s62\n\t"
-                "s_cmp_lt_u32 s66, 64\n\t"
-                "s_cbranch_scc1 4b\n"
-                // ---- the tile is walked: visited mask, tile counter
-                "7:\n\t"
-                "v_lshrrev_b64 v[40:41], %[sh32], %[Vo]\n\t"       // lane & 1 picks the word of the mask it stores
-                "v_add_u32_e32 v42, s81, %[avis]\n\t"
-                "v_mov_b32_e32 v43, %[actl]\n\t"
-                "v_mov_b32_e32 v44, s61\n\t"
-                "ds_write_b32 v42, v40\n\t"                        // record words 2, 3: the lanes the parse visited
-                "ds_write_b32 v43, v44 offset:20\n\t"              // ctl[5]: tiles walked
-                // ---- the next tile's record and ORBIT's counter for it
-                "s_add_i32 s82, %[slot], 1\n\t"
-                "s_cmp_lg_u32 s82, %[R]\n\t"
-                "s_cselect_b32 s82, s82, 0\n\t"
-                "s_mul_i32 s82, s82, %[recb]\n\t"
-                "s_bitcmp1_b32 %[t], 0\n\t"
-                "s_cselect_b32 s83, %[ceven], %[codd]\n\t"
-                "v_add_u32_e32 v46, s82, %[aarr]\n\t"
-                "v_add_u32_e32 v45, s83, v43\n\t"
-                "ds_read_b32 v62, v45\n\t"
-                "ds_read_b128 v[48:51], v46\n\t"
-                "ds_read_b128 v[52:55], v46 offset:1024\n\t"
-                "ds_read_b128 v[56:59], v46 offset:2048\n\t"
-                "ds_read_b64 v[60:61], v46 offset:3072\n\t"
-                "s_mov_b64 %[p3], s[70:71]\n\t"
-                "s_mov_b64 %[p2], s[68:69]\n\t"
-                "s_mov_b64 %[p1], %[Vo]\n\t"
-                "s_mov_b32 %[code], 0\n"
-                "9:"
-                : [code] "=&s"(code), [v] "+s"(v_u), [lastm] "+s"(lm_u), [p1] "+s"(vall_p1), [p2] "+s"(vall_p2), [p3] "+s"(vall_p3),
-                  [nearm] "=&s"(near_o), [certm] "=&s"(cert_o), [Vo] "=&s"(V_o), [Lo] "=&s"(L_o), [ph] "=&v"(prev_hit_o)
-                : [t] "s"(t), [slot] "s"(rec_slot), [actl] "s"(a_ctl), [tail] "s"(tail_from), [avis] "v"(a_vis), [aarr] "v"(a_arr), [sh32] "v"(sh32),
-                  [recb] "n"(StageCfg::REC_WORDS * 4u), [R] "n"(StageCfg::R), [ceven] "n"(kCtlOrbitEven * 4u), [codd] "n"(kCtlOrbitOdd * 4u)
-                : "scc", "memory", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76",
-                  "s77", "s78", "s79", "s80", "s81", "s82", "s83", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",
-                  "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
-            v = v_u; last_m = lm_u;
-#ifdef TSQ_X_WALK_COUNT
-            cnt_[code]++;
-#endif
-            if (code == 0u) { TSQ_TRACE_ALL(9, t); continue; }
-            // the compiled body goes on with the tile: the record from the fixed registers
-            asm volatile(
-                "v_mov_b32_e32 %0, v48\n\tv_mov_b32_e32 %1, v49\n\tv_mov_b32_e32 %2, v50\n\tv_mov_b32_e32 %3, v51\n\t"
-                "v_mov_b32_e32 %4, v52\n\tv_mov_b32_e32 %5, v54\n\tv_mov_b32_e32 %6, v55\n\t"
-                "v_mov_b32_e32 %7, v56\n\tv_mov_b32_e32 %8, v57\n\tv_mov_b32_e32 %9, v58\n\tv_mov_b32_e32 %10, v59\n\t"
-                "v_mov_b32_e32 %11, v60\n\tv_mov_b32_e32 %12, v61"
-                : "=v"(spanword), "=v"(lane_word), "=v"(orb_lo), "=v"(orb_hi), "=v"(nearw), "=v"(tin_lo), "=v"(tin_hi), "=v"(tp1_lo), "=v"(tp1_hi),
-                  "=v"(tp2r_lo), "=v"(tp2r_hi), "=v"(tp3r_lo), "=v"(tp3r_hi)
-                :: "memory");
-            nx = spanword >> 24;
-        }
-#endif
         const uint32_t base = t << 6;
         uint64_t vall = 0;
         // (the walk always enters the tile: a symbol spans at most 64 positions, so v <= base - 1 + 64 here -- no test, a branch costs
@@ -1454,7 +1195,6 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
             // bookkeeping): the LDS serves a wavefront's requests in order, so when the counter (asked for first) says the record is
             // there, the words that came back behind it are the record's; only when it was not there yet (the lag loop is late) are they
             // asked for again.
-#ifndef TSQ_WALK_ASM
             if (uniform(seen_v) < t + 1u) {
 #ifdef TSQ_STATS
                 const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
@@ -1465,27 +1205,18 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
 #endif
                 load_record(arr);
             }
-#endif
             TSQ_CNT(15, 1);
-#ifndef TSQ_WALK_ASM
             TSQ_TRACE(8, t);
-#endif
             const uint32_t settled = (spanword & 0x1000u) ? 0u : 0xFFFFFFFFu;     // ORBIT has settled the lane's twins in tiles t-LF .. t-LM+1
             const uint32_t tp2_lo = LF <= 2u ? tp2r_lo & settled : tp2r_lo, tp2_hi = LF <= 2u ? tp2r_hi & settled : tp2r_hi;
             const uint32_t tp3_lo = tp3r_lo & settled, tp3_hi = tp3r_hi & settled;
             uint64_t handed = 0;                 // visited lanes already handed to ACCOUNT (segments pushed in front of queries, and the query lanes)
-#ifdef TSQ_WALK_ASM
-            // (the hand-written block has made these)
-            const uint64_t near_m = near_o, certain_m = cert_o;
-            const uint32_t prev_hit = prev_hit_o;
-#else
             const uint64_t near_m = __ballot((spanword & 0x800u) != 0u);
             const uint64_t certain_m = __ballot((spanword & 0x400u) != 0u);
             // a twin visited in the previous tiles: fixed for the whole tile (kept per lane, it joins the in-tile test)
             uint32_t prev_hit = (tp1_lo & (uint32_t)vall_p1) | (tp1_hi & (uint32_t)(vall_p1 >> 32)) |
                                 (tp2_lo & (uint32_t)vall_p2) | (tp2_hi & (uint32_t)(vall_p2 >> 32));
             if (LM == 4u) prev_hit |= (tp3_lo & (uint32_t)vall_p3) | (tp3_hi & (uint32_t)(vall_p3 >> 32));
-#endif
             const uint32_t k0 = (spanword >> 16) & 0xFFu;
             const uint32_t cand0 = lane_word & 0xFFFFFFu;
 
@@ -1643,14 +1374,7 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                 L = v - base;
                 REG_END(5);
             };
-#ifdef TSQ_WALK_ASM
-            // (the hand-written block has walked the first segment unless a near-twin lane lay on the orbit)
-            // (code 1: stopped at a hazard lane it does not decide itself; code 2: in front of a segment with a near-twin lane on its orbit)
-            vall = V_o; L = L_o;
-            if (code != 1u) segment();
-#else
             segment();
-#endif
             while (L < 64u) {
                 hazard_lane();
                 if (L >= 64u || done != 0u) break;
@@ -1672,13 +1396,9 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
         stage_publish(ctl, 5, t + 1u, lane);
         {   // the next tile's record is requested now: its words travel while the loop's bookkeeping runs
             const uint32_t next_slot = rec_slot + 1u == StageCfg::R ? 0u : rec_slot + 1u;
-#ifdef TSQ_WALK_ASM
-            asm_preload(next_slot * StageCfg::REC_WORDS * 4u, ((t & 1u) ? kCtlOrbitEven : kCtlOrbitOdd) * 4u);
-#else
             seen_v = ((volatile lds_u32_t*)ctl)[orbit_word_after<EXT, WINDOW>(t)];
             load_record(recs + next_slot * StageCfg::REC_WORDS + StageCfg::ARR + lane * 4u);
             asm volatile("" ::: "memory");
-#endif
         }
 #ifdef TSQ_STATS
         if (lane == 0) ctl[40u + (t & 7u)] = (uint32_t)__builtin_amdgcn_s_memtime();       // (the lag loop is timed from here)
@@ -1689,9 +1409,6 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
     }
 #ifdef TSQ_STATS
     if (blockIdx.x == 0 && lane == 0) { g_enc_stats[8] = st_[8]; g_enc_stats[9] = st_[9]; g_enc_stats[10] = TSQ_TOTAL(); g_enc_stats[11] = st_[11]; g_enc_stats[12] = st_[12]; g_enc_stats[15] = st_[15]; for (int q = 23; q < 28; ++q) g_enc_stats[q] = st_[q]; g_enc_stats[29] = st_[17]; g_enc_stats[30] = st_[18]; g_enc_stats[31] = st_[19]; g_enc_stats[20] = st_[20]; g_enc_stats[40] = st_[10]; }
-#endif
-#ifdef TSQ_X_WALK_COUNT
-    if (blockIdx.x == 0 && lane == 0) printf("WALK hand-written block: tiles done %u, handed over mid-tile %u, near-twin %u\n", cnt_[0], cnt_[1], cnt_[2]);
 #endif
     __hip_atomic_store(&ctl[6], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     ev_push(kEvEnd, 0u, 0u, 0u);
@@ -1777,11 +1494,7 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
             asm volatile("v_writelane_b32 %0, %1, 8" : "+v"(hv) : "s"((uint32_t)(Mt >> 32)));
             // (every lane stores: lanes 9 .. 15 put the kind word into the item's unused words, lanes above 15 into word 15 -- cheaper
             //  than masking the wavefront down to nine lanes: no exec save / restore, no branch around an empty mask)
-#ifdef TSQ_X_HDRMASK
-            if (lane < 9u) it[lane] = hv;
-#else
             it[lane < 15u ? lane : 15u] = hv;
-#endif
             it[16 + lane] = lw;
             slot_publish();
         }

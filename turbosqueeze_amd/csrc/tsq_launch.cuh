@@ -2,7 +2,7 @@
 //
 // The product library carries three kernel families: the staged encoder (tsq_enc_stage.cuh: fourteen working wavefronts per block, twelve in the lean layout; standard and lean
 // layouts, with and without extensions), the byte-lane decoder (tsq_dec_sym.cuh, tsq_dec_duo.cuh) and the serial correctness
-// baselines (tsq_serial.cuh, variant 1).  The previous round's production encoder (ab/tsq_enc_stage_r04.cuh, encoder variant 5) is
+// baselines (tsq_serial.cuh, variant 1).  The previous round's production encoder (ab/tsq_enc_stage_r05.cuh, encoder variant 5) is
 // compiled only into the A/B library (`make ab`, -DTSQ_AB_VARIANTS), which tests/test_gpu_parity.py holds against the same oracle.
 #pragma once
 
@@ -16,7 +16,7 @@
 #include "tsq_dec_duo.cuh"
 #include "tsq_enc_stage.cuh"
 #ifdef TSQ_AB_VARIANTS
-#include "ab/tsq_enc_stage_r04.cuh"
+#include "ab/tsq_enc_stage_r05.cuh"
 #endif
 
 namespace tsq {
@@ -58,18 +58,18 @@ inline int launch_encode_kernels(tsqa_ctx* c, const uint8_t* in, size_t n, size_
         return 0;
     }
 #ifdef TSQ_AB_VARIANTS
-    if (v == 5) {                       // round 4's production encoder, frozen (ab/tsq_enc_stage_r04.cuh)
+    if (v == 5) {                       // round 5's production encoder, frozen (ab/tsq_enc_stage_r05.cuh)
         static std::atomic<uint64_t> ab_devices{0};
-        const void* const fns[4] = {reinterpret_cast<const void*>(r04::enc_stage_kernel<true, true>), reinterpret_cast<const void*>(r04::enc_stage_kernel<false, true>),
-                                    reinterpret_cast<const void*>(r04::enc_stage_kernel<true, false>), reinterpret_cast<const void*>(r04::enc_stage_kernel<false, false>)};
-        const uint32_t bytes[4] = {r04::StageCfgT<true>::total, r04::StageCfgT<true>::total, r04::StageCfgT<false>::total, r04::StageCfgT<false>::total};
+        const void* const fns[4] = {reinterpret_cast<const void*>(r05::enc_stage_kernel<true, true>), reinterpret_cast<const void*>(r05::enc_stage_kernel<false, true>),
+                                    reinterpret_cast<const void*>(r05::enc_stage_kernel<true, false>), reinterpret_cast<const void*>(r05::enc_stage_kernel<false, false>)};
+        const uint32_t bytes[4] = {r05::StageCfgT<true>::total, r05::StageCfgT<true>::total, r05::StageCfgT<false>::total, r05::StageCfgT<false>::total};
         if (int rc = raise_lds_limit(c, ab_devices, fns, bytes)) return rc;
         if (nb > (uint32_t)c->n_cus) {
-            if (ext) TSQ_LAUNCH_ENC((r04::enc_stage_kernel<true, false>), r04::StageCfgT<false>::THREADS_LEAN, r04::StageCfgT<false>::total);
-            else     TSQ_LAUNCH_ENC((r04::enc_stage_kernel<false, false>), r04::StageCfgT<false>::THREADS_LEAN, r04::StageCfgT<false>::total);
+            if (ext) TSQ_LAUNCH_ENC((r05::enc_stage_kernel<true, false>), r05::StageCfgT<false>::THREADS_LEAN, r05::StageCfgT<false>::total);
+            else     TSQ_LAUNCH_ENC((r05::enc_stage_kernel<false, false>), r05::StageCfgT<false>::THREADS_LEAN, r05::StageCfgT<false>::total);
         } else {
-            if (ext) TSQ_LAUNCH_ENC((r04::enc_stage_kernel<true, true>), r04::StageCfgT<true>::THREADS, r04::StageCfgT<true>::total);
-            else     TSQ_LAUNCH_ENC((r04::enc_stage_kernel<false, true>), r04::StageCfgT<true>::THREADS, r04::StageCfgT<true>::total);
+            if (ext) TSQ_LAUNCH_ENC((r05::enc_stage_kernel<true, true>), r05::StageCfgT<true>::THREADS, r05::StageCfgT<true>::total);
+            else     TSQ_LAUNCH_ENC((r05::enc_stage_kernel<false, true>), r05::StageCfgT<true>::THREADS, r05::StageCfgT<true>::total);
         }
         return 0;
     }

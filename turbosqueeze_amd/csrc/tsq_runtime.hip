@@ -40,6 +40,63 @@ extern "C" size_t tsqa_block_count(size_t n) { return (n + kBlockSize - 1) / kBl
 
 extern "C" size_t tsqa_container_bound(size_t n) { return 16 + tsqa_block_count(n) * (size_t)(3 + kSlotSize); }
 
+// What this library was compiled as (csrc/tsq_experiment.h): the product reports no timing-only switch and no instrumentation.
+#define TSQ_STR2(x) #x
+#define TSQ_STR(x) TSQ_STR2(x)
+extern "C" const char* tsqa_build_info(void)
+{
+    return "arch=gfx950 timing_only=" TSQ_STR(TSQ_TIMING_ONLY_BUILD) " instrumented=" TSQ_STR(TSQ_INSTRUMENTED_BUILD)
+#ifdef TSQ_AB_VARIANTS
+           " ab_variants=1"
+#else
+           " ab_variants=0"
+#endif
+           " lm=" TSQ_STR(TSQ_LM) " lf=" TSQ_STR(TSQ_LF) " records=" TSQ_STR(TSQ_RECORDS) " [switches:"
+#ifdef TSQ_X_NOHAZ
+           " TSQ_X_NOHAZ"
+#endif
+#ifdef TSQ_X_NOCOMMITWAIT
+           " TSQ_X_NOCOMMITWAIT"
+#endif
+#ifdef TSQ_X_NOPATCH
+           " TSQ_X_NOPATCH"
+#endif
+#ifdef TSQ_X_FAKE_TABLE
+           " TSQ_X_FAKE_TABLE"
+#endif
+#ifdef TSQ_X_FAKE_CAND
+           " TSQ_X_FAKE_CAND"
+#endif
+#ifdef TSQ_X_WALK_FREE_RECORD
+           " TSQ_X_WALK_FREE_RECORD"
+#endif
+#ifdef TSQ_X_FREE_QUERY
+           " TSQ_X_FREE_QUERY"
+#endif
+#ifdef TSQ_X_DEC_SKIP
+           " TSQ_X_DEC_SKIP"
+#endif
+#ifdef TSQ_X_DELAY_STAGE
+           " TSQ_X_DELAY_STAGE"
+#endif
+#ifdef TSQ_STATS
+           " TSQ_STATS"
+#endif
+#ifdef TSQ_SPINS
+           " TSQ_SPINS"
+#endif
+#ifdef TSQ_TRACEONLY
+           " TSQ_TRACEONLY"
+#endif
+#ifdef TSQ_JITTER
+           " TSQ_JITTER"
+#endif
+#if !TSQ_TIMING_ONLY_BUILD && !TSQ_INSTRUMENTED_BUILD
+           " none"
+#endif
+           "]";
+}
+
 extern "C" int tsqa_create(int device, tsqa_ctx** out)
 {
     if (!out) return TSQA_ERR_ARG;
