@@ -1179,24 +1179,10 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
     seen_v = ((volatile lds_u32_t*)ctl)[orbit_word<EXT, WINDOW>(0u)];
     load_record(recs + StageCfg::ARR + lane * 4u);
     asm volatile("" ::: "memory");
-#ifdef TSQ_X_WALK_FREE_RECORD
-    uint32_t fr_acc_seen = 0, fr_com_seen = 0;
-#endif
     TSQ_BEGIN();
     for (uint32_t t = 0; done == 0u; ++t, wbase = wbase + 64u == StageCfg::WIN ? 0u : wbase + 64u, rec_slot = rec_slot + 1u == StageCfg::R ? 0u : rec_slot + 1u) {
         const uint32_t base = t << 6;
         uint64_t vall = 0;
-#ifdef TSQ_X_WALK_FREE_RECORD
-        u32x4_t sh_a, sh_b, sh_c; u32x2_t sh_d;
-        // (WALK still never overwrites a visited mask that ACCOUNT or COMMIT has not read: in the product HASH's ring enforces that through ORBIT)
-        if (t + 2u > StageCfg::R) { if (!stage_wait_seen(ctl, kCtlAccounted, t + 2u - StageCfg::R, fr_acc_seen, 0) || !stage_wait_seen(ctl, kCtlCommitted, t + 2u - StageCfg::R, fr_com_seen, 0)) break; }
-        {
-            const uint32_t ns = rec_slot + 1u == StageCfg::R ? 0u : rec_slot + 1u;
-            volatile lds_u32_t* na = recs + ns * StageCfg::REC_WORDS + StageCfg::ARR + lane * 4u;
-            sh_a = lds_ld4(na + kGA); sh_b = lds_ld4(na + kGB); sh_c = lds_ld4(na + kGC); sh_d = lds_ld2(na + kGD);
-            asm volatile("" ::: "memory");
-        }
-#endif
         // (the walk always enters the tile: a symbol spans at most 64 positions, so v <= base - 1 + 64 here -- no test, a branch costs
         //  the serial stage as much as five instructions whether it is taken or not)
         {
@@ -1209,9 +1195,6 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
             // bookkeeping): the LDS serves a wavefront's requests in order, so when the counter (asked for first) says the record is
             // there, the words that came back behind it are the record's; only when it was not there yet (the lag loop is late) are they
             // asked for again.
-#ifdef TSQ_X_WALK_FREE_RECORD   // timing only (wrong streams): WALK never waits for its record -- the words asked for at the START of the previous tile are taken as they came
-            if (t < 2u * StageCfg::R || t + 2u * StageCfg::R >= (n >> 6))     // (the first records must exist, and the block's tail must be walked as it is)
-#endif
             if (uniform(seen_v) < t + 1u) {
 #ifdef TSQ_STATS
                 const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
@@ -1283,9 +1266,6 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
                     const uint64_t M = V & certain_m;
                     last_m = s_selnz64(M, base + s_msb64(M | 1ull), last_m);
                 }
-#ifdef TSQ_X_WALK_FREE_RECORD     // (a record taken before ORBIT has written it may name a halt behind the entry: the walk must still move on)
-                L = L < L0 ? L0 : L;
-#endif
                 vall |= V;
                 v = base + L;
                 REG_END(3);
@@ -1420,20 +1400,9 @@ __device__ __forceinline__ void stage_walk(const uint8_t* src, uint64_t avail, u
         stage_publish(ctl, 5, t + 1u, lane);
         {   // the next tile's record is requested now: its words travel while the loop's bookkeeping runs
             const uint32_t next_slot = rec_slot + 1u == StageCfg::R ? 0u : rec_slot + 1u;
-#ifdef TSQ_X_WALK_FREE_RECORD
-            if (t + 1u < 2u * StageCfg::R || t + 1u + 2u * StageCfg::R >= (n >> 6)) {
-                seen_v = ((volatile lds_u32_t*)ctl)[orbit_word_after<EXT, WINDOW>(t)];
-                load_record(recs + next_slot * StageCfg::REC_WORDS + StageCfg::ARR + lane * 4u);
-                asm volatile("" ::: "memory");
-            } else {
-            spanword = sh_a.x; lane_word = sh_a.y; orb_lo = sh_a.z; orb_hi = sh_a.w; nearw = sh_b.x; tin_lo = sh_b.z; tin_hi = sh_b.w;
-            tp1_lo = sh_c.x; tp1_hi = sh_c.y; tp2r_lo = sh_c.z; tp2r_hi = sh_c.w; tp3r_lo = sh_d.x; tp3r_hi = sh_d.y; nx = spanword >> 24;
-            }
-#else
             seen_v = ((volatile lds_u32_t*)ctl)[orbit_word_after<EXT, WINDOW>(t)];
             load_record(recs + next_slot * StageCfg::REC_WORDS + StageCfg::ARR + lane * 4u);
             asm volatile("" ::: "memory");
-#endif
         }
 #ifdef TSQ_STATS
         if (lane == 0) ctl[40u + (t & 7u)] = (uint32_t)__builtin_amdgcn_s_memtime();       // (the lag loop is timed from here)
@@ -1806,7 +1775,9 @@ __device__ __forceinline__ void stage_account(uint32_t n, lds_u8_t* lds, uint32_
     // loop body spends about twice that (flags through lane masks, register copies where its paths merge, a branch pair per test).
     // Whatever it does not handle leaves it untouched (code != 0) and goes through the compiled path below.  ACCOUNT and WALK are the two
     // wavefronts that pace the pipeline.  s[60:83] and v[40:47] are its scratch registers.
-#if !defined(TSQ_NO_ACCT_ASM) && !defined(TSQ_STATS) && !defined(TSQ_SPINS)
+// (instrumented builds keep it: `make stats` / `make spins` time and count the product's own path -- the waits are in snapshot(), which this
+    //  block falls back to whenever it would have to wait; only TSQ_CNT's per-tile counters inside the compiled path skip the tiles it takes)
+#if !defined(TSQ_NO_ACCT_ASM)
 #define TSQ_ACCT_ASM 1
     const uint32_t lds0 = (uint32_t)(size_t)lds;
     const uint32_t a_ctl = lds0 + StageCfg::off_ctl;                                                   // ctl[0]

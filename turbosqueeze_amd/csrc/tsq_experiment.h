@@ -12,7 +12,7 @@
 #pragma once
 
 #if defined(TSQ_X_NOHAZ) || defined(TSQ_X_NOCOMMITWAIT) || defined(TSQ_X_NOPATCH) || defined(TSQ_X_FAKE_TABLE) || defined(TSQ_X_FAKE_CAND) || \
-    defined(TSQ_X_WALK_FREE_RECORD) || defined(TSQ_X_FREE_QUERY) || defined(TSQ_X_DEC_SKIP)
+    defined(TSQ_X_FREE_QUERY)
 #define TSQ_TIMING_ONLY_BUILD 1
 #ifndef TSQ_EXPERIMENT
 #error "a timing-only switch (TSQ_X_*: wrong streams on purpose) needs -DTSQ_EXPERIMENT; the product library is never built with one (tools/xbuild.sh)"

@@ -67,14 +67,8 @@ extern "C" const char* tsqa_build_info(void)
 #ifdef TSQ_X_FAKE_CAND
            " TSQ_X_FAKE_CAND"
 #endif
-#ifdef TSQ_X_WALK_FREE_RECORD
-           " TSQ_X_WALK_FREE_RECORD"
-#endif
 #ifdef TSQ_X_FREE_QUERY
            " TSQ_X_FREE_QUERY"
-#endif
-#ifdef TSQ_X_DEC_SKIP
-           " TSQ_X_DEC_SKIP"
 #endif
 #ifdef TSQ_X_DELAY_STAGE
            " TSQ_X_DELAY_STAGE"
