@@ -56,3 +56,15 @@ dt = sum(d[:9])
 print(f"DEC block0: total ticks={dt} chunks={d[12]} retry rounds={d[13]} jump rounds={d[14]}  thread0: vector history loads={d[9]} bytewise history loads={d[10]} pending bytes at P6b start={d[11]} image bytes={d[15]}")
 for k, nm in enumerate(names):
     print(f"  {nm:16s} {d[k]:10d}  {100.0*d[k]/max(dt,1):5.1f}%  per chunk {d[k]/max(d[12],1):8.1f}")
+
+try:
+    w = (C.c_ulonglong * 48)()
+    L.tsqa_debug_dec_waves.argtypes = [C.c_void_p]
+    if L.tsqa_debug_dec_waves(w) == 0:
+        w = list(w); ch = max(d[12], 1)
+        print("  pointer jumping per wavefront of block 0 (cycles / waiting bytes / loop iterations per chunk):")
+        print("   " + "  ".join(f"w{k}: {w[3*k]/ch:.0f}/{w[3*k+1]/ch:.0f}/{w[3*k+2]/ch:.1f}" for k in range(16)))
+        cyc = [w[3*k] / ch for k in range(16)]
+        print(f"   mean {sum(cyc)/16:.0f}, max {max(cyc):.0f} cycles per chunk (the sum over chunks of the per-chunk maximum is what the barrier waits for)")
+except Exception as e:
+    print("  (no per-wavefront jump counters in this library)", e)

@@ -93,6 +93,13 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t v)
     TSQ_DPP_SCAN_STEP(dpp_add, 0x142, 0xA) TSQ_DPP_SCAN_STEP(dpp_add, 0x143, 0xC)      // row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3
     return v;
 }
+__device__ __forceinline__ uint32_t dpp_last(uint32_t own, uint32_t earlier) { return own ? own : earlier; }
+__device__ __forceinline__ uint32_t wave_scan_last(uint32_t v)                         // every lane: the last non-zero value at or before it (0: none)
+{
+    TSQ_DPP_SCAN_STEP(dpp_last, 0x111, 0xF) TSQ_DPP_SCAN_STEP(dpp_last, 0x112, 0xF) TSQ_DPP_SCAN_STEP(dpp_last, 0x114, 0xF) TSQ_DPP_SCAN_STEP(dpp_last, 0x118, 0xF)
+    TSQ_DPP_SCAN_STEP(dpp_last, 0x142, 0xA) TSQ_DPP_SCAN_STEP(dpp_last, 0x143, 0xC)
+    return v;
+}
 __device__ __forceinline__ uint32_t wave_scan_max(uint32_t v)                          // values >= 0; 0 is the identity
 {
     TSQ_DPP_SCAN_STEP(dpp_max, 0x111, 0xF) TSQ_DPP_SCAN_STEP(dpp_max, 0x112, 0xF) TSQ_DPP_SCAN_STEP(dpp_max, 0x114, 0xF) TSQ_DPP_SCAN_STEP(dpp_max, 0x118, 0xF)

@@ -14,6 +14,7 @@ struct DecSym {            // 8 bytes
 
 #ifdef TSQ_STATS
 __device__ unsigned long long g_dec_stats[16];
+__device__ unsigned long long g_dec_wave[48];      // per wavefront of block 0: cycles in the pointer jumping, waiting bytes, loop iterations
 #define TSQD_T0() unsigned long long t0_ = __builtin_amdgcn_s_memtime()
 #define TSQD_ACC(slot) do { unsigned long long t1_ = __builtin_amdgcn_s_memtime(); st_[slot] += t1_ - t0_; t0_ = t1_; } while (0)
 #define TSQD_CNT(slot, v) st_[slot] += (v)

@@ -73,20 +73,7 @@ struct SymLds {
     static constexpr uint32_t misc = wsum + 64;                                     // u32[16]
     static constexpr uint32_t lut = misc + 64;                                      // u16[1024]: (two control bits, size byte) -> stream bytes of the pair
     static constexpr uint32_t ring = (lut + 2048 + 15) & ~15u;                      // u8[R + RPAD]
-    // The pipelined decoder (dec_sym_kernel built with -DTSQ_DEC_PIPE; an experiment, off: bit-exact, and 4 - 6 % SLOWER -- 4.73 ms with the
-    // parse beside the pointer jumping, 4.80 beside the record scan, against 4.55: every wavefront runs the same sequence, so the next
-    // chunk's parse and this chunk's copy phases do not overlap inside a wavefront, and across wavefronts they are in the same phase at
-    // the same time): the NEXT chunk's stream is staged, and every offset of it parsed as a group start, while the
-    // current chunk's bytes are being resolved -- `stage` lies behind the symbol records in the part of the doubling tables that is dead
-    // during the copy phases, `j1x` (next - offset of the chunk after) behind the ring, where nothing overwrites it until its chunk is parsed.
-#ifdef TSQ_DEC_PIPE
-    static constexpr uint32_t stage = recw + 4 * (SymCfg::OUTC + 16);                // u8[S + SPAD + 16]: the next chunk's stream (P5 of this one)
-    static constexpr uint32_t j1x = ring + SymCfg::R + SymCfg::RPAD;                 // u8[S]
-    static constexpr uint32_t total = j1x + SymCfg::S;
-    static_assert(stage % 16 == 0 && stage + 16 * SymCfg::SWORDS <= gstart, "the staged stream fits behind the records");
-#else
     static constexpr uint32_t total = ring + SymCfg::R + SymCfg::RPAD;               // (the product asks for nothing it does not use)
-#endif
     static_assert(SymCfg::R % 16 == 0, "ring phase");
     static_assert(recw % 16 == 0 && recw + 4 * (SymCfg::OUTC + 16) <= gstart && plist % 16 == 0 && plist + 2 * SymCfg::OUTC <= gstart,
                   "records, byte entries and waiting lists fit the dead doubling tables");
@@ -120,12 +107,7 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
     using C = SymCfg;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t* const s_raw = lds + SymLds::sbuf;
-#ifndef TSQ_DEC_PIPE
     uint8_t* const j1 = lds + SymLds::j1;
-#else
-    uint8_t* const j1 = lds + SymLds::j1x;
-    uint16_t* const lut = reinterpret_cast<uint16_t*>(lds + SymLds::lut);
-#endif
     uint16_t* const j2 = reinterpret_cast<uint16_t*>(lds + SymLds::j2);
     uint16_t* const j4 = reinterpret_cast<uint16_t*>(lds + SymLds::j4);
     uint16_t* const j8 = reinterpret_cast<uint16_t*>(lds + SymLds::j8);
@@ -163,6 +145,7 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
 
 #ifdef TSQ_STATS
     unsigned long long st_[16] = {0};
+    unsigned long long wj_[3] = {0, 0, 0};
 #endif
     TSQD_T0();
     if (tid == 0) { misc[4] = 0; misc[9] = 0; misc[10] = 0; }
@@ -202,68 +185,30 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
         if (tid < C::SWORDS && (tid << 4) + 16u <= lim) __builtin_memcpy(&pre, in + at + (tid << 4), 16);
     };
     prefetch(sp);
-#ifdef TSQ_DEC_PIPE
-    // The chunk's stream into LDS at `dst` (sbuf[k] = in[at + k]; zeros beyond the stream): the words prefetched into registers, the
-    // stream's last, partial word byte by byte (once per block).
-    auto stage_chunk = [&](uint8_t* dst, uint32_t at) {
+    // the words prefetched into `pre` (chunk at stream offset `at`, `av` stream bytes from there) go to the stream buffer
+    auto stage_words = [&](uint32_t at, uint32_t av) {
         if (tid < C::SWORDS) {
             uint4 w = pre;
-            const uint32_t av = in_len - at;
             const uint32_t lim = av < C::S + C::SPAD ? av : C::S + C::SPAD, o = tid << 4;
-            if (o < lim && o + 16u > lim) {
+            if (o < lim && o + 16u > lim) {                                       // the stream's last, partial word (once per block)
                 uint32_t b[4] = {0, 0, 0, 0};
                 for (uint32_t k = 0; o + k < lim; ++k) b[k >> 2] |= (uint32_t)in[at + o + k] << (8u * (k & 3u));
                 w = make_uint4(b[0], b[1], b[2], b[3]);
             }
-            *reinterpret_cast<uint4*>(dst + (tid << 4)) = w;
+            *reinterpret_cast<uint4*>(s_raw + (tid << 4)) = w;
         }
     };
-    // P1 on the stream at `src`: every byte offset parsed AS IF a group started there -- the control byte, then per pair the size byte and
-    // the pair's stream length from the 2 KB table (two control bits, size byte) -- ; next - offset goes to j1.  (This form needs no
-    // scratch table over the doubling tables, which hold the current chunk's records while it runs.)
-    auto parse_every_offset = [&](const uint8_t* src) {
-        uint32_t x[C::PER], y[C::PER], c[C::PER];
-#pragma unroll
-        for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t o = tid + k * C::T; c[k] = src[o]; x[k] = o + 1u; }
-#pragma unroll
-        for (uint32_t pr = 0; pr < 4; ++pr) {
-#pragma unroll
-            for (uint32_t k = 0; k < C::PER; ++k) y[k] = src[x[k]];                        // x < S + 133: inside the padded buffer
-#pragma unroll
-            for (uint32_t k = 0; k < C::PER; ++k) y[k] = lut[(((c[k] >> (6u - 2u * pr)) & 3u) << 8) | y[k]];
-#pragma unroll
-            for (uint32_t k = 0; k < C::PER; ++k) x[k] += y[k];
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t o = tid + k * C::T; j1[o] = (uint8_t)(x[k] - o); }
-    };
-    { uint32_t sl, ol; pair_lens(tid & 255u, tid >> 8, 0u, sl, ol); lut[tid] = (uint16_t)sl; }
+    bool staged_ahead = false;
     __syncthreads();
-    // the first chunk: staged and parsed here; every later one while the chunk before it is being copied (below)
-    stage_chunk(s_raw, sp);
-    __syncthreads();
-    parse_every_offset(s_raw);
-#else
-    __syncthreads();
-#endif
 
     while (op < size) {
         const uint32_t avail = in_len - sp;
         const uint32_t slim = avail < C::S ? avail : C::S;
         uint8_t* const sbuf = s_raw;
-#ifndef TSQ_DEC_PIPE
         // ---------------- P0: the chunk (loaded a chunk ago) goes to LDS.  sbuf[k] = in[sp + k]; zeros beyond the stream.
-        if (tid < C::SWORDS) {
-            uint4 w = pre;
-            const uint32_t lim = avail < C::S + C::SPAD ? avail : C::S + C::SPAD, o = tid << 4;
-            if (o < lim && o + 16u > lim) {                                       // the stream's last, partial word (once per block)
-                uint32_t b[4] = {0, 0, 0, 0};
-                for (uint32_t k = 0; o + k < lim; ++k) b[k >> 2] |= (uint32_t)in[sp + o + k] << (8u * (k & 3u));
-                w = make_uint4(b[0], b[1], b[2], b[3]);
-            }
-            *reinterpret_cast<uint4*>(s_raw + (tid << 4)) = w;
-        }
-#endif
+        // (Only the block's first chunk is staged here: every later one goes to LDS behind the byte fetch of the chunk before it, beside
+        //  that chunk's pointer jumping -- the stream buffer is dead from there on, and the words have long arrived: `stage_next` below.)
+        if (!staged_ahead) stage_words(sp, avail);
         if (tid == 0) { misc[0] = 0; misc[1] = 0; misc[2] = 0xFFFFFFFFu; misc[3] = 0xFFFFFFFFu; misc[5] = 0; }
         // (pipelined: the chunk's stream is in sbuf and j1 holds its parse at every offset -- both made during the previous chunk's copy
         //  phases; this barrier also ends the previous chunk's ring write, which reads the byte entries the doubling tables now overwrite)
@@ -276,7 +221,6 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
         // pass.  An offset at or beyond slim is terminal (TERM).
         {
             uint32_t x[C::PER], y[C::PER];
-#ifndef TSQ_DEC_PIPE
             uint32_t c[C::PER];
             // (A) every byte of the chunk taken as a size byte: the stream length of the pair it would head, for each of the four
             //     control-bit pairs, packed in one word: 5 | 4 + lo << 8 | 4 + hi << 16 | 3 + hi + lo << 24 (tsq_decode.cpp:66-88: a
@@ -318,10 +262,6 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
 #pragma unroll
             for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t o = tid + k * C::T; j1[o] = (uint8_t)(x[k] - o); x[k] = o < slim ? x[k] : C::TERM; }
             __syncthreads();
-#else
-#pragma unroll
-            for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t o = tid + k * C::T; x[k] = o < slim ? o + j1[o] : C::TERM; }
-#endif
             TSQD_ACC(1);
 #pragma unroll
             for (uint32_t k = 0; k < C::PER; ++k) { const uint32_t a = x[k] < slim ? x[k] : 0u; y[k] = a + j1[a]; }
@@ -345,11 +285,18 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
         TSQD_ACC(2);
 
         // ---------------- P3: one lane follows next^16 from the chunk start  ||  P7 of the previous chunk on the other waves
-        if (tid == 0) {
+        if (wid == 0) {
+            // (the whole first wavefront walks, every lane the same chain: no lane mask to set up and restore; two hops per loop test --
+            //  the table's tail is a fixed point, so the second look-up is safe wherever the first one lands)
             uint32_t x = 0, k = 0;
-            while (x < slim && k < C::MAXSN) { sn[k++] = (uint16_t)x; x = j16[x]; }
-            misc[0] = k;
-            if (k >= C::MAXSN && x < slim) misc[4] = kErrStream;
+            while (x < slim && k < C::MAXSN) {
+                const uint32_t x1 = j16[x];
+                const uint32_t x2 = j16[x1];                                        // x1 <= TERM, and j16[TERM] == TERM
+                sn[k++] = (uint16_t)x;
+                if (x1 < slim && k < C::MAXSN) { sn[k++] = (uint16_t)x1; x = x2; }
+                else x = x1;
+            }
+            if (lane == 0) { misc[0] = k; if (k >= C::MAXSN && x < slim) misc[4] = kErrStream; }
         }
         __syncthreads();
         const uint32_t nsn = misc[0];
@@ -480,18 +427,9 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
             }
         }
         if (bad) misc[4] = kErrStream;
-#ifdef TSQ_DEC_PIPE
-        // ---- the next chunk (its stream was requested behind P4): staged behind the records now, parsed at every offset beside the
-        //      record scan below (vector work: the parse is LDS look-ups), copied to its place beside the ring write -- P0 and P1 of
-        //      chunk k+1 inside the copy phases of chunk k
-        if (!last_chunk) stage_chunk(lds + SymLds::stage, next_sp);
-#endif
         __syncthreads();
         if (misc[4] != 0) { if (tid == 0) atomicMax(status, (int32_t)misc[4]); return; }
         TSQD_ACC(5);
-#ifdef TSQ_DEC_PIPE
-        if (!last_chunk) parse_every_offset(lds + SymLds::stage);
-#endif
         // (b) one lane per 12 bytes: every byte takes the record of the symbol it lies in (the last record at or before it)
         typedef __attribute__((address_space(3))) uint16_t lds_u16;
         lds_u16* const le = (lds_u16*)(lds + SymLds::ent);                             // byte entries: 0x8000 | value when final, else source index
@@ -504,14 +442,12 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
             r[0] = q0.x; r[1] = q0.y; r[2] = q0.z; r[3] = q0.w; r[4] = q1.x; r[5] = q1.y; r[6] = q1.z; r[7] = q1.w; r[8] = q2.x; r[9] = q2.y; r[10] = q2.z; r[11] = q2.w;
 #pragma unroll
             for (uint32_t k = 1; k < 12; ++k) r[k] = r[k] ? r[k] : r[k - 1];
-            // the last record of the lanes before this one: a max-scan over "1 + lane if it holds a record" names the lane, one
-            // ds_bpermute fetches the record from it
-            const uint32_t key = wave_scan_max(r[11] ? lane + 1u : 0u);
-            const uint32_t from = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x138, 0xF, 0xF, false);      // wave_shr:1 : the lanes strictly before
-            uint32_t carry = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((from ? from - 1u : 0u) << 2), (int)r[11]);
-            carry = from ? carry : 0u;
-            const uint32_t upto = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((key ? key - 1u : 0u) << 2), (int)r[11]);   // (every lane takes part: a
-            if (lane == 63) wsum[wid] = key ? upto : 0u;                                                                      //  bpermute reads active lanes only)
+            // the last record of the lanes before this one: a scan with "the later non-zero word wins" over the lanes' last records
+            // (six DPP steps on the record itself; round 5 scanned a lane number and fetched the record with two ds_bpermute: two
+            // LDS round trips per chunk on every wavefront)
+            const uint32_t upto = wave_scan_last(r[11]);                                                            // inclusive
+            uint32_t carry = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)upto, 0x138, 0xF, 0xF, false);           // wave_shr:1 : the lanes strictly before
+            if (lane == 63) wsum[wid] = upto;
             __syncthreads();                                                       // (also: every lane has taken its records out of `recw`)
             {   // the last record of the wavefronts before this one: lane w looks at wavefront w's, the highest one that has any wins
                 const uint32_t ws = lane < 16u ? wsum[lane] : 0u;
@@ -556,6 +492,9 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
         }
         __syncthreads();
         TSQD_ACC(6);
+        // the NEXT chunk's stream goes to LDS now (P0 of chunk k + 1): nothing reads the stream buffer any more (the literal bytes were
+        // fetched above), and the words were requested behind P4, a dozen thousand cycles ago
+        if (!last_chunk) { stage_words(next_sp, in_len - next_sp); staged_ahead = true; }
         // (d) asynchronous pointer jumping, no barriers, one lane per waiting byte: it reads its source's entry; a final entry
         //     carries the value, any other entry is a pointer further back (entries only ever move towards the chain's root, so a
         //     stale read is still a valid ancestor).  Chains of any depth (every occurrence of a frequent word copies the one
@@ -565,6 +504,11 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
             // The list is padded to whole passes of 64 with a spare entry of this wavefront (final from the start: a lane that sits
             // on it re-writes what it read), and the loop is compiled for the number of passes so that it is straight-line code:
             // all reads of an iteration in flight together, no branches.
+            // (Round 6 tried two ways of evening out the wavefronts' lists -- the last wavefronts hold 340 waiting bytes per chunk, the
+            //  first 54, the ones beyond the image's end none: tools/phase_stats.py --: the image's rows of sixteen lanes dealt round the
+            //  wavefronts DOUBLES the loop's iterations, 4.74 ms against 4.49; ONE list for the workgroup cut into sixteen equal stretches
+            //  takes 900 cycles per chunk off this phase and puts 1 350 onto the one before it (a barrier and a prefix over the
+            //  wavefronts' counts in front of the list's stores), 4.52 against 4.46.)
             const uint32_t spare = C::OUTC + wid;
             if (lane == 0) le[spare] = 0x8000u;
             const uint32_t passes = (n_wait + 63u) >> 6;
@@ -572,6 +516,7 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
             if (passes) for (uint32_t it = n_wait + lane; it < padded * 64u; it += 64u) wl[it] = (uint16_t)spare;
 #ifdef TSQ_STATS
             uint32_t iters_ = 0;
+            const unsigned long long wj0_ = __builtin_amdgcn_s_memtime();
 #endif
             auto jump = [&](auto passes_c) {
                 constexpr uint32_t P = decltype(passes_c)::value;
@@ -604,6 +549,8 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
             else jump(std::integral_constant<uint32_t, 12>{});
 #ifdef TSQ_STATS
             if (lane == 0) { atomicMax(&misc[9], iters_); atomicAdd(&misc[10], n_wait); }
+            // per wavefront: when it left the pointer jumping (imbalance between the wavefronts shows as the barrier wait behind it)
+            if (lane == 0 && blockIdx.x == 0) { wj_[0] += __builtin_amdgcn_s_memtime() - wj0_; wj_[1] += n_wait; wj_[2] += iters_; }
 #endif
         }
         __syncthreads();
@@ -618,10 +565,6 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
                 *reinterpret_cast<uint32_t*>(ring + x) = (lo & 0xFFu) | ((lo >> 8) & 0xFF00u) | ((hi & 0xFFu) << 16) | ((hi >> 16) << 24);
             }
         }
-#ifdef TSQ_DEC_PIPE
-        if (!last_chunk && tid < C::SWORDS)
-            *reinterpret_cast<uint4*>(s_raw + (tid << 4)) = *reinterpret_cast<const uint4*>(lds + SymLds::stage + (tid << 4));
-#endif
         // (no barrier here: nothing reads the ring, and nothing overwrites the entries, before the barrier at the top of the next chunk)
         TSQD_ACC(7);
 #ifdef TSQ_STATS
@@ -640,6 +583,7 @@ __global__ __launch_bounds__(1024) void dec_sym_kernel(const uint8_t* __restrict
     flush_image(0, C::T);
 #ifdef TSQ_STATS
     if (blockIdx.x == 0 && tid == 0) for (int q = 0; q < 16; ++q) g_dec_stats[q] = st_[q];
+    if (blockIdx.x == 0 && lane == 0) for (int q = 0; q < 3; ++q) g_dec_wave[wid * 3 + q] = wj_[q];
 #endif
 }
 

@@ -758,6 +758,10 @@ extern "C" int tsqa_debug_stats(unsigned long long* enc64, unsigned long long* d
     if (dec16 && hipMemcpyFromSymbol(dec16, HIP_SYMBOL(tsq::g_dec_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return TSQA_ERR_HIP;
     return TSQA_OK;
 }
+extern "C" int tsqa_debug_dec_waves(unsigned long long* out48)
+{
+    return hipMemcpyFromSymbol(out48, HIP_SYMBOL(tsq::g_dec_wave), 48 * sizeof(unsigned long long)) == hipSuccess ? TSQA_OK : TSQA_ERR_HIP;
+}
 extern "C" int tsqa_debug_duo_xcc(uint32_t* out2048)
 {
     return hipMemcpyFromSymbol(out2048, HIP_SYMBOL(tsq::g_duo_xcc), 2048 * sizeof(uint32_t)) == hipSuccess ? TSQA_OK : TSQA_ERR_HIP;
