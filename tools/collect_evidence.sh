@@ -12,6 +12,7 @@ bash tools/profile_round.sh $TAG > $OUT/profile_round.log 2>&1
 cp $OUT/pmc_summary.json profiles/${TAG}_pmc_fetch_write.json
 (timeout 600 python bench.py --steps 10 --warmup 3 2>&1 | tail -1) > $OUT/bench.json
 python tools/phase_stats.py > $OUT/phase_stats.txt 2>&1
+(timeout 300 python tools/tile_trace.py 2>&1 | tail -60) > $OUT/tile_trace.txt
 python tools/traffic_experiment.py > $OUT/traffic_experiment.jsonl 2>/dev/null
 (cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
  for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --kernel-trace --pmc $c -d $OUT/traffic_$c -o t --output-format csv -- python tools/traffic_experiment.py > /dev/null 2>&1; done
@@ -42,7 +43,10 @@ timeout 300 python tools/config5_sweep.py 1342177280 1 0 mix 2>/dev/null >> $OUT
 timeout 300 python tools/config5_sweep.py 4294967296 0 0 text 2>/dev/null >> $OUT/config5.jsonl
 for args in "--synthetic 1000000000 --reps 5 --no-ext" "--synthetic 1000000000 --reps 5" "--synthetic 4000000000 --reps 3"; do timeout 300 tools/tsq_cli b $args 2>/dev/null | tail -1; done > $OUT/cli_host_buffers.json
 tools/micro/lds_unaligned > $OUT/lds_access_costs.txt 2>&1
-TSQ_BENCH_BACKEND=gloo TSQ_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --steps 5 --warmup 2 --no-weak 2>/dev/null | tail -1 > $OUT/bench_2ranks_1gpu.json
+# the N > 1 line on this 1-GPU box: `python bench.py --gpus N` typed plainly launches its N ranks itself; here they share GPU 0 over gloo (a dry run of the
+# code path, not a scaling measurement: N processes time-slice one GPU and one PCIe link)
+TSQ_BENCH_BACKEND=gloo TSQ_BENCH_SHARE_GPU=1 timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_2ranks_1gpu.json
+TSQ_BENCH_BACKEND=gloo TSQ_BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 8 --steps 2 --warmup 1 --size 2000000000 --ext 1 --kind mix 2>/dev/null | tail -1 > $OUT/bench_8ranks_1gpu.json
 (TSQ_AMD_DEBUG=1 timeout 200 tools/tsq_cli b --synthetic 1000000000 --reps 2 --no-ext 2>&1 | tail -45) > $OUT/cli_timeline.txt
 mkdir -p gpurun_out/x; bash tools/bottleneck.sh run > $OUT/bottleneck.txt 2>&1
 python tools/spin_counts.py > $OUT/spin_counts.txt 2>&1

@@ -32,3 +32,4 @@ ls -la profiles/${TAG}_*
 [ -f $S/sq_icache.txt ] && grep -v amdgpu.ids $S/sq_icache.txt > profiles/${TAG}_sq_icache.txt
 for f in tile_trace_zeros_ext1 tile_trace_lean_random_ext1 fuzz_variants; do [ -f $S/$f.txt ] && grep -v amdgpu.ids $S/$f.txt > profiles/${TAG}_$f.txt; done
 true
+cp $S/bench_8ranks_1gpu.json profiles/${TAG}_bench_8ranks_1gpu.json 2>/dev/null || true

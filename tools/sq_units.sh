@@ -15,7 +15,7 @@ for fn in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"].split("(")[0]
         if "enc_stage" in k or "dec_sym" in k:
             # keyed by kernel AND launch shape (blocks = grid size / workgroup size), like tools/pmc_summary.py: the profiled command also
-            # launches both kernels at 1 024 blocks (`throughput`)
+            # launches both kernels at 1 024 blocks (the throughput job)
             try:
                 blocks = int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)
             except Exception:
