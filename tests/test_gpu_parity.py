@@ -513,6 +513,17 @@ def test_sharded_decode_stall_is_retried(tsq, oracle):
         c.sharded_decode_again_async(blocks.slots, d_back)
         torch.cuda.synchronize()
         assert c.status() == 0
+        # a retry is bound to the buffers of the call it repeats, and to that call being the context's last use of its frame
+        # descriptors: other buffers, or a retry after an ordinary decompress on the same context, are refused
+        other = torch.zeros_like(d_back)
+        with pytest.raises(tsq.TsqError) as e:
+            c.sharded_decode_again_async(blocks.slots, other)
+        assert e.value.code == 3, e.value
+        blob = c.compress(torch.from_numpy(host[:3 * B]).cuda(), 0)
+        assert torch.equal(c.decompress(blob), torch.from_numpy(host[:3 * B]).cuda())
+        with pytest.raises(tsq.TsqError) as e:
+            c.sharded_decode_again_async(blocks.slots, d_back)
+        assert e.value.code == 3, e.value
     finally:
         c.close()
         hc.close()
